@@ -1,0 +1,173 @@
+"""
+ctypes binding of libpi_mi355.so (C ABI: include/pi_mi355.h).
+
+The library is the only compute path of this package.  There is no CPU or eager
+fallback: if the shared object is missing or fails to load, importing this module
+still succeeds (so ``load()``-only workflows work on machines without ROCm) but
+``lib()`` raises, and so does every solver constructor.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libpi_mi355.so"
+KERNEL_CACHE = Path(os.environ.get("PI_MI355_KERNEL_CACHE", str(_PKG / "_kcache")))
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/pi_mi355.h declares.
+SIGNATURES = {
+    "pi_abi_version": (ctypes.c_int, []),
+    "pi_last_error": (ctypes.c_char_p, []),
+    "pi_create": (_vp, [ctypes.c_int, ctypes.c_int, _i32p, _f32p, _f32p,
+                        ctypes.POINTER(_f32p), _f32p, ctypes.c_int]),
+    "pi_destroy": (None, [_vp]),
+    "pi_compile": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                  ctypes.c_size_t]),
+    "pi_kernel_source": (ctypes.c_size_t, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]),
+    "pi_eval_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_float, _vp, _vp]),
+    "pi_eval_sweeps": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_float, ctypes.c_int, _vp, _vp]),
+    "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_float, _vp, _vp]),
+    "pi_probe_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "pi_probe_interp": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
+}
+
+ABI_VERSION = 1
+_lib = None
+_load_error: Exception | None = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises NativeError (never falls back) when unavailable."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise NativeError(str(_load_error)) from _load_error
+    try:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C dynamicprogramming_amd/csrc`")
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pi_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libpi_mi355 ABI {handle.pi_abi_version()} != binding {ABI_VERSION}")
+        _lib = handle
+        return _lib
+    except Exception as exc:  # noqa: BLE001 - recorded and re-raised on every call
+        _load_error = exc
+        raise NativeError(f"libpi_mi355.so unavailable: {exc}") from exc
+
+
+def available() -> bool:
+    try:
+        lib()
+        return True
+    except NativeError:
+        return False
+
+
+def last_error() -> str:
+    return lib().pi_last_error().decode(errors="replace")
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeError(f"{what} failed: {last_error()}")
+
+
+class Engine:
+    """One pi_handle: a grid + action set + (after compile) its specialised kernels."""
+
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, device: int = -1):
+        L = lib()
+        self.D = int(D)
+        self._shape = np.ascontiguousarray(grid_shape, dtype=np.int32)
+        self._lo = np.ascontiguousarray(lo, dtype=np.float32)
+        self._hi = np.ascontiguousarray(hi, dtype=np.float32)
+        self._bins = [np.ascontiguousarray(b, dtype=np.float32) for b in bins]
+        self._actions = np.ascontiguousarray(actions, dtype=np.float32)
+        assert len(self._bins) == self.D and all(len(b) == g for b, g in zip(self._bins, self._shape))
+        arr = (_f32p * self.D)(*[b.ctypes.data_as(_f32p) for b in self._bins])
+        self._h = L.pi_create(int(device), self.D, self._shape.ctypes.data_as(_i32p),
+                              self._lo.ctypes.data_as(_f32p), self._hi.ctypes.data_as(_f32p), arr,
+                              self._actions.ctypes.data_as(_f32p), len(self._actions))
+        if not self._h:
+            raise NativeError(f"pi_create failed: {last_error()}")
+        self.device = int(device)
+        self.n_states = int(L.pi_info(self._h, 0))
+        self.compile_log = ""
+
+    # -- compilation ---------------------------------------------------------
+    def kernel_source(self, dynamics_src: str) -> str:
+        L = lib()
+        src = dynamics_src.encode()
+        n = L.pi_kernel_source(self._h, src, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        L.pi_kernel_source(self._h, src, buf, n + 1)
+        return buf.value.decode()
+
+    def compile(self, dynamics_src: str, cache_dir: Path | str | None = KERNEL_CACHE) -> None:
+        L = lib()
+        log = ctypes.create_string_buffer(1 << 16)
+        cdir = None
+        if cache_dir is not None:
+            Path(cache_dir).mkdir(parents=True, exist_ok=True)
+            cdir = str(cache_dir).encode()
+        rc = L.pi_compile(self._h, dynamics_src.encode(), cdir, log, len(log))
+        self.compile_log = log.value.decode(errors="replace")
+        if rc != 0:
+            raise NativeError(f"kernel compilation failed:\n{last_error()}")
+
+    def info(self, what: int) -> int:
+        return int(lib().pi_info(self._h, what))
+
+    # -- launches (raw device pointers; all asynchronous on `stream`) ---------
+    def eval_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta=0, stream=0):
+        _check(lib().pi_eval_sweep(self._h, V, Vnew, policy, term, s_begin, s_end, gamma,
+                                   d_delta or None, stream or None), "pi_eval_sweep")
+
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta=0, stream=0):
+        _check(lib().pi_eval_sweeps(self._h, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps,
+                                    d_delta or None, stream or None), "pi_eval_sweeps")
+
+    def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
+        _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,
+                                      d_changed or None, stream or None), "pi_improve_sweep")
+
+    def probe_step(self, states, acts, nxt, reward, done, m, stream=0):
+        _check(lib().pi_probe_step(self._h, states, acts, nxt, reward, done, m, stream or None),
+               "pi_probe_step")
+
+    def probe_interp(self, pts, idxs, wgts, m, stream=0):
+        _check(lib().pi_probe_interp(self._h, pts, idxs, wgts, m, stream or None), "pi_probe_interp")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().pi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

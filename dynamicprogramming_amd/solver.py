@@ -1,0 +1,405 @@
+"""
+Policy-iteration solver for MI355X — host side.
+
+Public surface = the reference's (src/cuda_policy_iteration.py): ``CudaPIConfig`` (:36-43)
+and ``CudaPolicyIteration{2D,4D,6D}`` with ``__init__(bins_space, action_space, config)``,
+the subclass hooks ``_dynamics_cuda_src()`` / ``_terminal_fn(states)`` /
+``_allocate_tensors_and_compile()``, and ``run()``, ``policy_evaluation()``,
+``policy_improvement()``, ``save()``, ``load()``; same attributes after ``run()``/``load()``
+and the same ``.npz`` schema (:397-408).  A runner written against the reference imports
+``src.cuda_policy_iteration`` (a shim onto this module) and works unchanged.
+
+Underneath nothing is shared with the reference: the grid is described by D bin tables,
+V / policy / mask live in torch-ROCm tensors (device memory only), and every sweep is one
+call through the ctypes C ABI of libpi_mi355.so (include/pi_mi355.h), whose hipRTC-built
+gfx950 kernels fuse the backup, the residual reduction and the policy-change count.
+With more than one rank (``torch.distributed`` initialised, one process per GPU) the flat
+state range is split into contiguous shards; each rank sweeps its shard and the V shards
+are all-gathered (RCCL over xGMI) after every evaluation sweep.
+
+There is no CPU or eager fallback: constructing a solver without the native library and
+a GPU raises ``RuntimeError`` exactly where the reference raises for a missing CuPy (:71-75).
+"""
+from __future__ import annotations
+
+import abc
+import logging
+import time
+from dataclasses import dataclass
+from itertools import product
+from pathlib import Path
+
+import numpy as np
+
+from . import _native
+
+try:  # the reference logs through loguru; use it when present, stdlib logging otherwise
+    from loguru import logger  # type: ignore
+except ImportError:  # pragma: no cover - loguru is absent on the build/GPU images
+    logger = logging.getLogger("dynamicprogramming_amd")
+    if not hasattr(logger, "success"):
+        logger.success = logger.info  # type: ignore[attr-defined]
+
+
+def _gpu_available() -> bool:
+    if not _native.available():
+        return False
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:  # noqa: BLE001
+        return False
+
+
+GPU_AVAILABLE = _gpu_available()
+
+SYNC_INTERVAL = 25   # the reference looks at the residual on sweeps 0, 25, 50, ... (:303, :325)
+
+
+@dataclass
+class CudaPIConfig:
+    """Solver settings; the five reference fields (:36-43) with the reference defaults."""
+    gamma: float = 0.99           # discount factor
+    theta: float = 1e-4           # residual threshold that ends a policy evaluation
+    max_eval_iter: int = 10_000   # sweeps per policy evaluation, at most
+    max_pi_iter: int = 50         # outer evaluate/improve iterations, at most
+    log_interval: int = 100       # log the residual every N sweeps (at check points)
+
+
+class HipSweepBackend:
+    """Sweeps through libpi_mi355.so on one GPU.  Tensors are torch-ROCm device tensors;
+    launches go on torch's current stream so torch-side ops and events order with them."""
+
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None):
+        import torch
+        if not _native.available():
+            raise RuntimeError("libpi_mi355.so is not available: " + _native_reason())
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm GPU visible to torch")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
+                                   else torch.device(device).index or 0)
+        self.engine = _native.Engine(D, grid_shape, lo, hi, bins, actions, device=self.device.index)
+        t0 = time.perf_counter()
+        self.engine.compile(dynamics_src)
+        self.compile_seconds = time.perf_counter() - t0
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
+        self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
+                                s_begin, s_end, gamma, n_sweeps,
+                                0 if d_delta is None else d_delta.data_ptr(), self._stream())
+
+    def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
+        self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), term.data_ptr(), s_begin, s_end,
+                                  gamma, 0 if d_changed is None else d_changed.data_ptr(),
+                                  self._stream())
+
+    def close(self):
+        self.engine.close()
+
+
+def _native_reason() -> str:
+    try:
+        _native.lib()
+        return ""
+    except _native.NativeError as exc:
+        return str(exc)
+
+
+class _CudaPolicyIterationBase(abc.ABC):
+    """Shared implementation; the public classes fix ``_D``."""
+
+    _D: int = 0
+
+    def __init__(self, bins_space: dict, action_space, config: CudaPIConfig | None = None, *,
+                 device=None, process_group=None, backend_factory=None) -> None:
+        """
+        bins_space   : dict with exactly D keys -> 1-D arrays of grid points (insertion order
+                       = dimension order), e.g. {"theta": linspace(-pi, pi, 200), ...}
+        action_space : 1-D array of scalar action values
+        config       : CudaPIConfig
+        device       : torch device of this rank (default: current CUDA device)
+        process_group: torch.distributed group to shard over (default: WORLD if initialised)
+        backend_factory : sweep-backend constructor; tests inject a CPU checker here, the
+                       product default is the HIP backend and is never replaced silently.
+        """
+        if backend_factory is None and not GPU_AVAILABLE:
+            raise RuntimeError(
+                f"{type(self).__name__} needs libpi_mi355.so and a ROCm GPU (MI355X, gfx950): "
+                + (_native_reason() or "torch.cuda.is_available() is False"))
+        self.config = config or CudaPIConfig()
+        self.action_space = np.ascontiguousarray(action_space, dtype=np.float32)
+        self.n_actions = len(self.action_space)
+
+        keys = list(bins_space.keys())
+        assert len(keys) == self._D, (
+            f"{type(self).__name__} requires exactly {self._D} state dimensions.")
+        # float32 grid points: states_space[:, d] takes exactly these values (:84-87).
+        self._bins = [np.asarray(bins_space[k]).astype(np.float32).ravel() for k in keys]
+        self._bin_keys = keys
+        self.n_states = int(np.prod([len(b) for b in self._bins], dtype=np.int64))
+        self._states_space = None
+        self._device_arg = device
+        self._process_group = process_group
+        self._backend_factory = backend_factory
+        self.stats = {"eval_sweeps": 0, "improve_sweeps": 0, "pi_iterations": 0,
+                      "sweeps_per_iter": [], "eval_seconds": 0.0, "improve_seconds": 0.0}
+
+        self._precompute_grid_metadata()
+        self._allocate_tensors_and_compile()
+
+    # ── grid ────────────────────────────────────────────────────────────────────────
+    @property
+    def states_space(self) -> np.ndarray:
+        """(n_states, D) float32 grid nodes, row-major with the last dimension fastest
+        (:84-87, :482-489, :896-904).  Built on first use: the device never needs it."""
+        if self._states_space is None:
+            grids = np.meshgrid(*self._bins, indexing="ij")
+            self._states_space = np.column_stack([g.ravel() for g in grids]).astype(np.float32)
+        return self._states_space
+
+    @states_space.setter
+    def states_space(self, value) -> None:
+        self._states_space = value
+
+    def _precompute_grid_metadata(self) -> None:
+        # Same quantities as :95-109 / :497-514 / :912-937, from the bin tables instead of
+        # the materialised (n, D) array (min/max/unique of a column = those of its table).
+        D = self._D
+        self.bounds_low = np.array([b.min() for b in self._bins], dtype=np.float32)
+        self.bounds_high = np.array([b.max() for b in self._bins], dtype=np.float32)
+        self.grid_shape = np.array([len(np.unique(b)) for b in self._bins], dtype=np.int32)
+        for d, b in enumerate(self._bins):
+            if self.grid_shape[d] != len(b):
+                raise ValueError(f"dimension {d} ({self._bin_keys[d]!r}) has repeated grid points")
+            if len(b) < 2:
+                raise ValueError(f"dimension {d} ({self._bin_keys[d]!r}) needs at least 2 grid points")
+        if self.n_states >= 2 ** 31:
+            raise ValueError("n_states must be < 2^31 (flat indices are int32, as in the reference)")
+        strides = np.ones(D, dtype=np.int64)
+        for d in range(D - 2, -1, -1):
+            strides[d] = strides[d + 1] * self.grid_shape[d + 1]
+        self.strides = strides.astype(np.int32)
+        self.corner_bits = np.array(list(product([0, 1], repeat=D)), dtype=np.int32)
+        logger.info(f"Grid: shape={self.grid_shape.tolist()}, states={self.n_states:,}, "
+                    f"actions={self.n_actions}")
+
+    # ── plugin surface ──────────────────────────────────────────────────────────────
+    @abc.abstractmethod
+    def _dynamics_cuda_src(self) -> str:
+        """C source defining ``__device__ void step_dynamics(...)`` with the arity for D
+        (2D: s0,s1,action,*ns0,*ns1,*reward,*terminated; 4D/6D likewise).  Helper
+        ``__device__`` functions and ``#define``s are allowed; the text is placed in front of
+        the generic kernels and compiled for gfx950."""
+
+    def _terminal_fn(self, states: np.ndarray):
+        """(bool mask over grid nodes, scalar terminal value); default: no terminal states."""
+        return np.zeros(len(states), dtype=bool), 0.0
+
+    # ── device state ────────────────────────────────────────────────────────────────
+    def _allocate_tensors_and_compile(self) -> None:
+        import torch
+        logger.info("Allocating device tensors and compiling gfx950 kernels...")
+        factory = self._backend_factory or HipSweepBackend
+        self._backend = factory(self._D, self.grid_shape, self.bounds_low, self.bounds_high,
+                                self._bins, self.action_space, self._dynamics_cuda_src(),
+                                device=self._device_arg)
+        dev = self._backend.device
+        self._init_sharding()
+
+        n, n_pad = self.n_states, self._n_pad
+        self.d_policy = torch.zeros(n_pad, dtype=torch.int32, device=dev)
+        self.d_value_function = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.d_new_value_function = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self._d_delta = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._d_changed = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        overridden = type(self)._terminal_fn is not _CudaPolicyIterationBase._terminal_fn
+        if overridden:
+            terminal_mask, terminal_value = self._terminal_fn(self.states_space)
+            terminal_mask = np.ascontiguousarray(terminal_mask, dtype=bool)
+        else:
+            terminal_mask, terminal_value = None, 0.0
+        self.d_terminal_mask = torch.zeros(n_pad, dtype=torch.uint8, device=dev)
+        if terminal_mask is not None and terminal_mask.any():
+            self.d_terminal_mask[:n] = torch.from_numpy(terminal_mask.view(np.uint8)).to(dev)
+            self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
+            logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
+        self.d_new_value_function.copy_(self.d_value_function)
+        logger.success("Kernels compiled. Device memory allocated.")
+
+    def _seed_values(self, mask: np.ndarray, value: float) -> None:
+        """Set V (both Jacobi buffers) on the masked grid nodes — supported way to give goal
+        cells a non-zero starting value (the crane runner does this by reaching into cupy,
+        runners/overhead_crane_cuda.py:193-206)."""
+        import torch
+        m = torch.from_numpy(np.ascontiguousarray(mask, dtype=bool)).to(self.d_value_function.device)
+        self.d_value_function[: self.n_states][m] = float(value)
+        self.d_new_value_function[: self.n_states][m] = float(value)
+
+    # ── sharding over ranks ─────────────────────────────────────────────────────────
+    def _init_sharding(self) -> None:
+        import torch.distributed as dist
+        group = self._process_group
+        if dist.is_available() and dist.is_initialized():
+            self._world = dist.get_world_size(group)
+            self._rank = dist.get_rank(group)
+        else:
+            self._world, self._rank = 1, 0
+        n = self.n_states
+        per = -(-n // self._world)              # ceil: equal shards, the tail is padding
+        self._shard_len = per
+        self._n_pad = per * self._world
+        self._s_begin = min(self._rank * per, n)
+        self._s_end = min(self._s_begin + per, n)
+        if self._world > 1:
+            logger.info(f"rank {self._rank}/{self._world}: states [{self._s_begin:,}, {self._s_end:,})")
+
+    def _all_gather_shards(self, full) -> None:
+        """Every rank contributes full[rank*per:(rank+1)*per]; afterwards all ranks hold all."""
+        import torch.distributed as dist
+        per = self._shard_len
+        mine = full[self._rank * per:(self._rank + 1) * per]
+        if full.device.type != "cuda":
+            mine = mine.clone()                 # gloo: no aliasing between input and output
+        dist.all_gather_into_tensor(full, mine, group=self._process_group)
+
+    def _all_reduce_scalar(self, t, op) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op), group=self._process_group)
+
+    # ── policy iteration ────────────────────────────────────────────────────────────
+    def policy_evaluation(self) -> float:
+        """Jacobi sweeps under the current policy until the residual, looked at on sweeps
+        0, 25, 50, ... and the last one, drops below theta (:300-336)."""
+        cfg = self.config
+        gamma = float(np.float32(cfg.gamma))
+        delta = float("inf")
+        t0 = time.perf_counter()
+        i = 0
+        sweeps = 0
+        while i < cfg.max_eval_iter:
+            check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
+            check = min(check, cfg.max_eval_iter - 1)
+            n = check - i + 1
+            if self._world == 1:
+                self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                          self.d_policy, self.d_terminal_mask, self._s_begin,
+                                          self._s_end, gamma, n, self._d_delta)
+                if n & 1:
+                    self.d_value_function, self.d_new_value_function = (
+                        self.d_new_value_function, self.d_value_function)
+            else:
+                for k in range(n):
+                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                              self.d_policy, self.d_terminal_mask, self._s_begin,
+                                              self._s_end, gamma, 1,
+                                              self._d_delta if k == n - 1 else None)
+                    self._all_gather_shards(self.d_new_value_function)
+                    self.d_value_function, self.d_new_value_function = (
+                        self.d_new_value_function, self.d_value_function)
+                self._all_reduce_scalar(self._d_delta, "MAX")
+            sweeps += n
+            i = check + 1
+            delta = float(self._d_delta.item())          # the one host sync per 25 sweeps
+            if check % cfg.log_interval == 0:
+                logger.debug(f"  Eval iter {check:5d} | delta = {delta:.4e}")
+            if delta < cfg.theta:
+                logger.success(f"  Eval converged at iter {check} | delta = {delta:.2e}")
+                break
+        else:
+            logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+        self.stats["eval_sweeps"] += sweeps
+        self.stats["sweeps_per_iter"].append(sweeps)
+        self.stats["eval_seconds"] += time.perf_counter() - t0
+        return delta
+
+    def policy_improvement(self) -> bool:
+        """Greedy improvement against the latest V; True when no entry changed (:338-355)."""
+        t0 = time.perf_counter()
+        gamma = float(np.float32(self.config.gamma))
+        self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
+                                    self._s_begin, self._s_end, gamma, self._d_changed)
+        if self._world > 1:
+            self._all_reduce_scalar(self._d_changed, "SUM")
+        changed = int(self._d_changed.item())
+        self.stats["improve_sweeps"] += 1
+        self.stats["last_changed"] = changed
+        self.stats["improve_seconds"] += time.perf_counter() - t0
+        return changed == 0
+
+    def run(self) -> None:
+        """Evaluate / improve until the policy is stable or max_pi_iter is reached (:357-370)."""
+        for n in range(self.config.max_pi_iter):
+            logger.info(f"-- PI Iteration {n + 1}/{self.config.max_pi_iter} --")
+            self.policy_evaluation()
+            self.stats["pi_iterations"] = n + 1
+            if self.policy_improvement():
+                logger.success(f"Policy Iteration converged at iteration {n + 1}.")
+                self.stats["stable"] = True
+                break
+        else:
+            logger.warning(f"Policy Iteration hit max_pi_iter={self.config.max_pi_iter}.")
+            self.stats["stable"] = False
+        self._pull_tensors_from_gpu()
+
+    def _pull_tensors_from_gpu(self) -> None:
+        """Copy V and the policy to host arrays and drop every device array (:372-388)."""
+        logger.info("Pulling results from device memory...")
+        if self._world > 1:
+            self._all_gather_shards(self.d_policy)
+        n = self.n_states
+        self.value_function = self.d_value_function[:n].cpu().numpy()
+        self.policy = self.d_policy[:n].cpu().numpy()
+        for attr in ["d_terminal_mask", "d_value_function", "d_new_value_function", "d_policy",
+                     "_d_delta", "_d_changed"]:
+            if hasattr(self, attr):
+                delattr(self, attr)
+        self._backend.close()
+        logger.success("Device memory released. Results in host memory.")
+
+    # ── persistence (schema of :392-432) ────────────────────────────────────────────
+    def save(self, filepath) -> None:
+        filepath = Path(filepath).with_suffix(".npz")
+        filepath.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(filepath, value_function=self.value_function, policy=self.policy,
+                 bounds_low=self.bounds_low, bounds_high=self.bounds_high,
+                 grid_shape=self.grid_shape, strides=self.strides, corner_bits=self.corner_bits,
+                 action_space=self.action_space, states_space=self.states_space)
+        logger.success(f"Policy saved to {filepath.resolve()}")
+
+    @classmethod
+    def load(cls, filepath):
+        """Rebuild an instance from a saved archive; needs neither a GPU nor the library."""
+        filepath = Path(filepath).with_suffix(".npz")
+        data = np.load(filepath)
+        inst = cls.__new__(cls)
+        inst._states_space = None
+        for key in ("value_function", "policy", "bounds_low", "bounds_high", "grid_shape",
+                    "strides", "corner_bits", "action_space"):
+            setattr(inst, key, data[key])
+        inst.states_space = data["states_space"]
+        inst.n_actions = len(inst.action_space)
+        inst.n_states = len(inst.states_space)
+        inst.config = CudaPIConfig()
+        logger.success(f"Policy loaded from {filepath.resolve()}")
+        return inst
+
+
+class CudaPolicyIteration2D(_CudaPolicyIterationBase):
+    """2-D grids (reference class :46-432); ``step_dynamics(s0, s1, action, *ns0, *ns1,
+    *reward, *terminated)``; 4-corner interpolation."""
+    _D = 2
+
+
+class CudaPolicyIteration4D(_CudaPolicyIterationBase):
+    """4-D grids (reference class :439-840); 16-corner interpolation."""
+    _D = 4
+
+
+class CudaPolicyIteration6D(_CudaPolicyIterationBase):
+    """6-D grids (reference class :847-1272); 64-corner interpolation."""
+    _D = 6
