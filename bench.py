@@ -1,0 +1,208 @@
+"""
+bench.py — state-action Bellman backups/s of the policy-iteration hot path on MI355X.
+
+Workload (BASELINE.json metric config, SURVEY.md §8d "C4"): double-pendulum swing-up, 4-D
+grid 80^4 = 40.96 M states x 11 torques, gamma 0.999, fp32.  Synthetic inputs: V ~ N(0,1),
+policy ~ U{0..10} (seeded), no terminal states (the env has none).  Everything is resident
+in HBM before the timed region.
+
+A STEP = one pass of the hot path over the whole grid in the sweep mix of SURVEY §8(d)'s
+protocol (100 evaluation + 10 improvement sweeps): 10 evaluation sweeps (each with the fused
+residual on the last) followed by 1 greedy improvement sweep (with the fused changed-count)
+= 10 n + 11 n = 21 n state-action backups, through the product path (solver -> C ABI -> HIP).
+
+N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): one process per GPU, the
+SAME grid sharded into N contiguous state ranges (strong scaling), V shards all-gathered over
+RCCL/xGMI after every evaluation sweep — the solver's own multi-rank path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), plus
+  roofline     — dominant kernel = pi_eval_sweep_kernel; algorithmic bytes/backup from
+                 SURVEY §8(d): 4*2^D + 4*D + 9 = 89 B (4-D), one backup per state per launch;
+                 achieved = 89 B * states-per-launch / mean launch time (HIP events on the
+                 launch stream around each 10-sweep group); peak = 8 TB/s HBM3E.
+  cpu_baseline — the oracle (oracle/pi_oracle.cpp, OpenMP) on the same workload restricted
+                 to a bounded sample of states, on this box's host cores (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ENV = "double_pendulum_swingup"
+BINS = 80
+EVAL_PER_STEP = 10
+IMPROVE_PER_STEP = 1
+
+
+def algorithmic_bytes_eval(D: int) -> int:
+    return 4 * (1 << D) + 4 * D + 9          # 89 B for D = 4
+
+
+def cpu_baseline(bins: int, sample_states: int, seed: int = 0) -> dict:
+    """Oracle timed on host cores over states [0, sample) of the same grid / V / policy."""
+    import oracle
+    from dynamicprogramming_amd import envs
+    cls = envs.ENVS[ENV]
+    tables = [np.asarray(b, np.float32) for b in cls.bins_space(bins).values()]
+    lo, hi, shape, strides = oracle.grid_metadata(tables)
+    n = int(np.prod(shape))
+    m = min(sample_states, n)
+    idx = np.stack(np.unravel_index(np.arange(m), tuple(shape)), axis=1)
+    states = np.stack([tables[d][idx[:, d]] for d in range(len(tables))], axis=1).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal(n).astype(np.float32)
+    pol = rng.integers(0, len(cls.ACTIONS), size=m).astype(np.int32)
+    term = np.zeros(m, dtype=np.uint8)
+    chk = oracle.build(cls._D, envs.dynamics_source(ENV))
+    gamma = np.float32(cls.CONFIG["gamma"])
+    out = np.zeros(m, dtype=np.float32)
+    chk.eval_sweep(states, cls.ACTIONS, pol, V, term, lo, hi, shape, strides, gamma, 0, m, out=out)  # warm
+    t0 = time.perf_counter()
+    for _ in range(EVAL_PER_STEP):
+        chk.eval_sweep(states, cls.ACTIONS, pol, V, term, lo, hi, shape, strides, gamma, 0, m, out=out)
+    for _ in range(IMPROVE_PER_STEP):
+        chk.improve_sweep(states, cls.ACTIONS, pol, V, term, lo, hi, shape, strides, gamma, 0, m)
+    dt = time.perf_counter() - t0
+    backups = m * (EVAL_PER_STEP + IMPROVE_PER_STEP * len(cls.ACTIONS))
+    threads = len(os.sched_getaffinity(0))
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    if env_threads:
+        threads = min(threads, int(env_threads))
+    return {"value": backups / dt, "unit": "backups/s", "cores": threads, "kind": "port",
+            "sample": f"one step (10 eval + 1 improve sweeps) over states [0, {m}) of the same "
+                      f"{bins}^4 grid, oracle/pi_oracle.cpp with OpenMP, {dt:.1f} s wall"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bins", type=int, default=BINS, help="grid points per dimension (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 21)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dynamicprogramming_amd import envs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cls = envs.ENVS[ENV]
+    solver = envs.make(ENV, args.bins, device=dev)
+    n, nA, D = solver.n_states, solver.n_actions, cls._D
+    gamma = float(np.float32(solver.config.gamma))
+
+    # synthetic resident inputs (identical on every rank)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32)
+    P0 = torch.randint(0, nA, (n,), generator=gen, dtype=torch.int32)
+    solver.d_value_function[:n].copy_(V0)
+    solver.d_new_value_function.copy_(solver.d_value_function)
+    solver.d_policy[:n].copy_(P0)
+    del V0, P0
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        solver._evaluation_sweeps(EVAL_PER_STEP, gamma)
+        if k is not None:
+            ev[k][1].record()
+        solver._improvement_sweep(gamma)
+        if k is not None:
+            ev[k][2].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    eval_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) / EVAL_PER_STEP
+    improve_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / IMPROVE_PER_STEP
+    # sanity: the sweeps really ran (residual and change count of the last step)
+    last_delta = float(solver._d_delta.item())
+    last_changed = int(solver._d_changed.item())
+
+    backups_per_step = n * (EVAL_PER_STEP + IMPROVE_PER_STEP * nA)
+    value = backups_per_step * args.steps / elapsed
+    states_per_launch = solver._s_end - solver._s_begin
+    bytes_eval = algorithmic_bytes_eval(D)
+    achieved = bytes_eval * states_per_launch / (eval_ms * 1e-3) / 1e9
+    bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
+    out = {
+        "metric": "state-action Bellman backups/sec",
+        "value": value,
+        "unit": "backups/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"double-pendulum swing-up 4D grid bins={args.bins}/dim "
+                               f"({n} states) x {nA} actions, gamma=0.999; step = {EVAL_PER_STEP} "
+                               f"eval sweeps + {IMPROVE_PER_STEP} improve sweep = {backups_per_step} backups",
+                   "states": n, "actions": nA, "eval_sweeps_per_step": EVAL_PER_STEP,
+                   "improve_sweeps_per_step": IMPROVE_PER_STEP,
+                   "parallelism": f"state-range shards x{world}" + (", RCCL all-gather of V per eval sweep" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "kernel": "pi_eval_sweep_kernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_backup": bytes_eval, "backups_per_launch": states_per_launch,
+                     "avg_launch_ms": eval_ms},
+        "eval_backups_per_s": states_per_launch * world / (eval_ms * 1e-3),
+        "improve_backups_per_s": states_per_launch * world * nA / (improve_ms * 1e-3),
+        "improve_roofline": {"achieved": bytes_improve * states_per_launch * nA / (improve_ms * 1e-3) / 1e9,
+                             "bytes_per_backup": bytes_improve, "avg_launch_ms": improve_ms},
+        "check": {"last_residual": last_delta, "last_changed": last_changed,
+                  "vgpr_eval": solver._backend.engine.info(4), "vgpr_improve": solver._backend.engine.info(5)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -272,6 +272,34 @@ class _CudaPolicyIterationBase(abc.ABC):
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op), group=self._process_group)
 
     # ── policy iteration ────────────────────────────────────────────────────────────
+    def _evaluation_sweeps(self, n: int, gamma: float) -> None:
+        """n Jacobi sweeps under the current policy; afterwards ``d_value_function`` is the
+        newest iterate and ``_d_delta`` holds the residual of the last sweep (max over ranks)."""
+        if self._world == 1:
+            self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                      self.d_policy, self.d_terminal_mask, self._s_begin,
+                                      self._s_end, gamma, n, self._d_delta)
+            if n & 1:
+                self.d_value_function, self.d_new_value_function = (
+                    self.d_new_value_function, self.d_value_function)
+            return
+        for k in range(n):
+            self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                      self.d_policy, self.d_terminal_mask, self._s_begin,
+                                      self._s_end, gamma, 1, self._d_delta if k == n - 1 else None)
+            self._all_gather_shards(self.d_new_value_function)
+            self.d_value_function, self.d_new_value_function = (
+                self.d_new_value_function, self.d_value_function)
+        self._all_reduce_scalar(self._d_delta, "MAX")
+
+    def _improvement_sweep(self, gamma: float) -> None:
+        """One greedy improvement of this rank's shard; ``_d_changed`` = entries changed (sum
+        over ranks)."""
+        self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
+                                    self._s_begin, self._s_end, gamma, self._d_changed)
+        if self._world > 1:
+            self._all_reduce_scalar(self._d_changed, "SUM")
+
     def policy_evaluation(self) -> float:
         """Jacobi sweeps under the current policy until the residual, looked at on sweeps
         0, 25, 50, ... and the last one, drops below theta (:300-336)."""
@@ -285,23 +313,7 @@ class _CudaPolicyIterationBase(abc.ABC):
             check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
             check = min(check, cfg.max_eval_iter - 1)
             n = check - i + 1
-            if self._world == 1:
-                self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                          self.d_policy, self.d_terminal_mask, self._s_begin,
-                                          self._s_end, gamma, n, self._d_delta)
-                if n & 1:
-                    self.d_value_function, self.d_new_value_function = (
-                        self.d_new_value_function, self.d_value_function)
-            else:
-                for k in range(n):
-                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                              self.d_policy, self.d_terminal_mask, self._s_begin,
-                                              self._s_end, gamma, 1,
-                                              self._d_delta if k == n - 1 else None)
-                    self._all_gather_shards(self.d_new_value_function)
-                    self.d_value_function, self.d_new_value_function = (
-                        self.d_new_value_function, self.d_value_function)
-                self._all_reduce_scalar(self._d_delta, "MAX")
+            self._evaluation_sweeps(n, gamma)
             sweeps += n
             i = check + 1
             delta = float(self._d_delta.item())          # the one host sync per 25 sweeps
@@ -321,10 +333,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         """Greedy improvement against the latest V; True when no entry changed (:338-355)."""
         t0 = time.perf_counter()
         gamma = float(np.float32(self.config.gamma))
-        self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
-                                    self._s_begin, self._s_end, gamma, self._d_changed)
-        if self._world > 1:
-            self._all_reduce_scalar(self._d_changed, "SUM")
+        self._improvement_sweep(gamma)
         changed = int(self._d_changed.item())
         self.stats["improve_sweeps"] += 1
         self.stats["last_changed"] = changed

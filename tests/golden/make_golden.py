@@ -34,6 +34,7 @@ sys.path.insert(0, str(ROOT))
 import oracle  # noqa: E402
 from oracle import build_ref  # noqa: E402
 from dynamicprogramming_amd import envs  # noqa: E402
+from tests.helpers import env_bins, sample_states, terminal_mask  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 
@@ -42,43 +43,6 @@ TINY_GRIDS = {
     4: [(7, 7, 7, 7), (9, 7, 11, 5)],
     6: [(4, 4, 4, 4, 4, 4), (5, 4, 6, 4, 5, 4)],
 }
-
-
-def env_bins(name: str, shape) -> list[np.ndarray]:
-    cls = envs.ENVS[name]
-    out = []
-    for d, g in enumerate(shape):
-        space = cls.bins_space(int(g))
-        out.append(np.asarray(list(space.values())[d], dtype=np.float32))
-    return out
-
-
-def terminal_mask(name: str, states: np.ndarray):
-    cls = envs.ENVS[name]
-    inst = object.__new__(cls)
-    if name == "overhead_crane":
-        inst.target_x = 0.0
-    if cls._terminal_fn is envs.CudaPolicyIteration2D._terminal_fn:
-        return np.zeros(len(states), dtype=bool), 0.0
-    mask, val = cls._terminal_fn(inst, states)
-    return np.asarray(mask, dtype=bool), float(val)
-
-
-def sample_states(rng, bins, m):
-    """Seeded query points: inside the grid, beyond its borders, on nodes, in the last cell."""
-    D = len(bins)
-    lo = np.array([b.min() for b in bins], dtype=np.float64)
-    hi = np.array([b.max() for b in bins], dtype=np.float64)
-    span = hi - lo
-    pts = lo + span * rng.uniform(-0.15, 1.15, size=(m, D))
-    k = m // 8
-    nodes = np.stack([b[rng.integers(0, len(b), size=k)] for b in bins], axis=1)
-    pts[:k] = nodes                                           # exact grid nodes
-    pts[k:2 * k] = hi - span * rng.uniform(0, 1e-3, size=(k, D))   # last cell
-    pts[2 * k:3 * k] = lo + span * rng.uniform(0, 1e-3, size=(k, D))  # first cell
-    pts[3 * k] = hi
-    pts[3 * k + 1] = lo
-    return pts.astype(np.float32)
 
 
 def assert_same(a, b, what):
@@ -98,7 +62,7 @@ def make_env(name: str) -> dict:
     D = cls._D
     ref = build_ref.load(name)
     port = oracle.build(D, envs.dynamics_source(name), libm=True)
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+    rng = np.random.default_rng(sum(map(ord, name)))
     actions = np.asarray(cls.ACTIONS, dtype=np.float32)
     gamma = np.float32(cls.CONFIG["gamma"])
     out: dict = {"actions": actions, "gamma": gamma, "D": np.int32(D)}

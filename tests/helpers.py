@@ -1,0 +1,131 @@
+"""Shared helpers for the test-suite (grids, masks, bit-level comparisons, checker backend)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+import oracle
+from dynamicprogramming_amd import envs
+from dynamicprogramming_amd.solver import _CudaPolicyIterationBase
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+ENV_NAMES = list(envs.ENVS)
+
+
+def env_bins(name: str, shape) -> list[np.ndarray]:
+    """The env's reference grid ranges with shape[d] points in dimension d."""
+    cls = envs.ENVS[name]
+    out = []
+    for d, g in enumerate(shape):
+        space = cls.bins_space(int(g))
+        out.append(np.asarray(list(space.values())[d], dtype=np.float32))
+    return out
+
+
+def env_bins_space(name: str, shape) -> dict:
+    cls = envs.ENVS[name]
+    keys = list(cls.bins_space(2).keys())
+    return dict(zip(keys, env_bins(name, shape)))
+
+
+def terminal_mask(name: str, states: np.ndarray):
+    cls = envs.ENVS[name]
+    inst = object.__new__(cls)
+    if name == "overhead_crane":
+        inst.target_x = 0.0
+    if cls._terminal_fn is _CudaPolicyIterationBase._terminal_fn:
+        return np.zeros(len(states), dtype=bool), 0.0
+    mask, val = cls._terminal_fn(inst, states)
+    return np.asarray(mask, dtype=bool), float(val)
+
+
+def sample_states(rng, bins, m):
+    """Seeded query points: inside the grid, beyond its borders, on nodes, in the edge cells."""
+    D = len(bins)
+    lo = np.array([b.min() for b in bins], dtype=np.float64)
+    hi = np.array([b.max() for b in bins], dtype=np.float64)
+    span = hi - lo
+    pts = lo + span * rng.uniform(-0.15, 1.15, size=(m, D))
+    k = m // 8
+    nodes = np.stack([b[rng.integers(0, len(b), size=k)] for b in bins], axis=1)
+    pts[:k] = nodes
+    pts[k:2 * k] = hi - span * rng.uniform(0, 1e-3, size=(k, D))
+    pts[2 * k:3 * k] = lo + span * rng.uniform(0, 1e-3, size=(k, D))
+    pts[3 * k] = hi
+    pts[3 * k + 1] = lo
+    return pts.astype(np.float32)
+
+
+def bits_equal(a, b) -> bool:
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype == np.float32 and b.dtype == np.float32:
+        return bool(np.array_equal(a.view(np.uint32), b.view(np.uint32))
+                    or np.array_equal(a, b, equal_nan=True))
+    return bool(np.array_equal(a, b))
+
+
+def assert_bits_equal(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    if not bits_equal(a, b):
+        bad = np.flatnonzero((a != b).ravel())
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} entries differ; first at {bad[:5]}: "
+                             f"{a.ravel()[bad[:5]]} vs {b.ravel()[bad[:5]]}")
+
+
+def golden(name: str):
+    return np.load(GOLDEN / f"{name}.npz")
+
+
+def oracle_for(name: str, libm: bool = False) -> oracle.OracleLib:
+    return oracle.build(envs.ENVS[name]._D, envs.dynamics_source(name), libm=libm)
+
+
+class OracleSweepBackend:
+    """CPU stand-in for HipSweepBackend, for HOST-LOGIC tests only (run-loop semantics,
+    sharding over gloo ranks).  Lives under tests/ so the product can never pick it up; it
+    is injected explicitly through the solver's ``backend_factory`` argument."""
+
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.lib = oracle.build(int(D), dynamics_src)
+        self.lo, self.hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+        self.shape = np.asarray(grid_shape, np.int32)
+        st = np.ones(int(D), dtype=np.int64)
+        for d in range(int(D) - 2, -1, -1):
+            st[d] = st[d + 1] * self.shape[d + 1]
+        self.strides = st.astype(np.int32)
+        self.actions = np.asarray(actions, np.float32)
+        self.states = oracle.states_from_bins(bins)
+        self.n = len(self.states)
+        self.calls = {"eval": 0, "improve": 0}
+
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
+        n = self.n
+        for i in range(n_sweeps):
+            src, dst = (Vb, Va) if (i & 1) else (Va, Vb)
+            out = dst.numpy()
+            _, delta = self.lib.eval_sweep(self.states, self.actions, policy.numpy()[:n],
+                                           src.numpy()[:n], term.numpy()[:n], self.lo, self.hi,
+                                           self.shape, self.strides, gamma, s_begin, s_end,
+                                           out=out[:n])
+            self.calls["eval"] += 1
+            if d_delta is not None and i == n_sweeps - 1:
+                d_delta[0] = delta
+
+    def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
+        n = self.n
+        new_pol, changed = self.lib.improve_sweep(self.states, self.actions, policy.numpy()[:n],
+                                                  V.numpy()[:n], term.numpy()[:n], self.lo, self.hi,
+                                                  self.shape, self.strides, gamma, s_begin, s_end)
+        policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+        self.calls["improve"] += 1
+        if d_changed is not None:
+            d_changed[0] = changed
+
+    def close(self):
+        pass

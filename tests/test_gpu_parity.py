@@ -1,0 +1,325 @@
+"""
+GPU parity: the HIP path (through the C ABI of libpi_mi355.so) against the CPU oracle.
+
+Bar (north_star): greedy-policy indices bit-exact; V within a stated fp32 tolerance.  Because
+the kernels and the oracle share include/pi_math.h and neither contracts fp32 operations, the
+tests below ask for more: V, residuals and change counts are compared BIT FOR BIT against the
+oracle built in the product's arithmetic mode.  Against the reference-text goldens (glibc
+libm) the tolerance is written out: |dV| <= 2e-4 * max(1, |V|) and policy equal wherever the
+top-2 action-value gap exceeds 1e-3.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+from dynamicprogramming_amd import _native, envs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _engine(name, shape, dev, actions=None):
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS if actions is None else actions, np.float32)
+    eng = _native.Engine(cls._D, [len(b) for b in bins], [b.min() for b in bins],
+                         [b.max() for b in bins], bins, acts, device=dev.index or 0)
+    eng.compile(envs.dynamics_source(name))
+    return eng, bins, acts
+
+
+def _dev(a, dev):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_dynamics_bit_exact(name, cuda_device):
+    """step_dynamics on the GPU == the same string on the CPU (pi_math mode), bit for bit."""
+    torch = _torch()
+    g = H.golden(name)
+    D = int(g["D"])
+    eng, bins, _ = _engine(name, H.golden(name)["g0_shape"], cuda_device)
+    rng = np.random.default_rng(7)
+    st = np.concatenate([g["step_states"], H.sample_states(rng, bins, 4096)])
+    act = np.concatenate([g["step_actions"],
+                          rng.choice(envs.ENVS[name].ACTIONS, size=4096).astype(np.float32)])
+    m = len(st)
+    d_st, d_act = _dev(st, cuda_device), _dev(act, cuda_device)
+    d_next = torch.empty((m, D), dtype=torch.float32, device=cuda_device)
+    d_rew = torch.empty(m, dtype=torch.float32, device=cuda_device)
+    d_done = torch.empty(m, dtype=torch.uint8, device=cuda_device)
+    eng.probe_step(d_st.data_ptr(), d_act.data_ptr(), d_next.data_ptr(), d_rew.data_ptr(),
+                   d_done.data_ptr(), m)
+    torch.cuda.synchronize()
+    o_next, o_rew, o_done = H.oracle_for(name).step(st, act)
+    H.assert_bits_equal(d_next.cpu().numpy(), o_next, f"{name} next state")
+    H.assert_bits_equal(d_rew.cpu().numpy(), o_rew, f"{name} reward")
+    assert np.array_equal(d_done.cpu().numpy().astype(bool), o_done)
+    # against the reference-text golden (glibc libm): ulp-level agreement only
+    k = len(g["step_states"])
+    np.testing.assert_allclose(d_next.cpu().numpy()[:k], g["step_next"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(d_rew.cpu().numpy()[:k], g["step_reward"], rtol=2e-4, atol=2e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["pendulum", "double_pendulum_swingup", "double_cartpole"])
+@pytest.mark.parametrize("gi", [0, 1])
+def test_interpolation_matches_reference_golden(name, gi, cuda_device):
+    """get_barycentric_{2,4,6}d: indices AND weights equal the reference-text golden exactly
+    (no transcendental is involved, so libm does not matter)."""
+    torch = _torch()
+    g = H.golden(name)
+    D = int(g["D"])
+    eng, _, _ = _engine(name, g[f"g{gi}_shape"], cuda_device)
+    pts = g[f"g{gi}_pts"]
+    m = len(pts)
+    d_idx = torch.empty((m, 1 << D), dtype=torch.int32, device=cuda_device)
+    d_w = torch.empty((m, 1 << D), dtype=torch.float32, device=cuda_device)
+    eng.probe_interp(_dev(pts, cuda_device).data_ptr(), d_idx.data_ptr(), d_w.data_ptr(), m)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_idx.cpu().numpy(), g[f"g{gi}_idx"])
+    H.assert_bits_equal(d_w.cpu().numpy(), g[f"g{gi}_w"], f"{name} weights")
+    eng.close()
+
+
+def _sweep_case(name, shape, dev, seed=0, actions=None):
+    eng, bins, acts = _engine(name, shape, dev, actions)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    term, tval = H.terminal_mask(name, states)
+    rng = np.random.default_rng(seed)
+    V = (rng.standard_normal(len(states)) * 3.0).astype(np.float32)
+    V[term] = np.float32(tval)
+    pol = rng.integers(0, len(acts), size=len(states)).astype(np.int32)
+    pol[term] = 0
+    return eng, acts, (lo, hi, gshape, strides), states, term, V, pol
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+@pytest.mark.parametrize("gi", [0, 1])
+def test_sweeps_bit_exact_and_golden(name, gi, cuda_device):
+    torch = _torch()
+    g = H.golden(name)
+    shape = g[f"g{gi}_shape"]
+    eng, bins, acts = _engine(name, shape, cuda_device)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    V, pol, term = g[f"g{gi}_V"], g[f"g{gi}_policy"], g[f"g{gi}_term"]
+    gamma = float(g["gamma"])
+    n = len(V)
+    d_V, d_pol = _dev(V, cuda_device), _dev(pol, cuda_device)
+    d_term = _dev(term.astype(np.uint8), cuda_device)
+    d_Vn = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    d_delta = torch.full((1,), 123.0, dtype=torch.float32, device=cuda_device)
+    d_changed = torch.full((1,), 77, dtype=torch.int32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n,
+                   gamma, d_delta.data_ptr())
+    eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                      d_changed.data_ptr())
+    torch.cuda.synchronize()
+    Vn, pol_n = d_Vn.cpu().numpy(), d_pol.cpu().numpy()
+    chk = H.oracle_for(name)
+    o_Vn, o_delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    o_pol, o_changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    # bit-exact against the oracle in the product's arithmetic
+    H.assert_bits_equal(Vn, o_Vn, f"{name} V'")
+    assert np.float32(d_delta.item()) == np.float32(o_delta)
+    assert np.array_equal(pol_n, o_pol)
+    assert int(d_changed.item()) == o_changed
+    # reference-text golden (glibc libm): stated tolerance
+    gV = g[f"g{gi}_V_next"]
+    assert np.all(np.abs(Vn - gV) <= 2e-4 * np.maximum(1.0, np.abs(gV)))
+    firm = g[f"g{gi}_q_gap"] > 1e-3
+    assert np.array_equal(pol_n[firm], g[f"g{gi}_policy_next"][firm])
+    assert np.mean(pol_n == g[f"g{gi}_policy_next"]) >= 0.995
+    eng.close()
+
+
+@pytest.mark.parametrize("name,shape", [("pendulum", (200, 200)), ("cartpole_swingup", (17, 13, 19, 11)),
+                                         ("double_pendulum_swingup", (20, 20, 20, 20)),
+                                         ("double_cartpole", (7, 6, 8, 5, 7, 6))])
+def test_ragged_ranges_and_pingpong(name, shape, cuda_device):
+    """Sub-range sweeps (shard boundaries not multiples of 256, empty ranges) touch exactly
+    their range, and pi_eval_sweeps ping-pongs like repeated single sweeps."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, 3)
+    n = len(V)
+    gamma = float(np.float32(envs.ENVS[name].CONFIG["gamma"]))
+    d_V, d_pol = _dev(V, cuda_device), _dev(pol, cuda_device)
+    d_term = _dev(term.astype(np.uint8), cuda_device)
+    chk = H.oracle_for(name)
+    cuts = [0, 1, 255, 257, n // 3, n // 3, n - 1, n]
+    d_Vn = torch.full((n,), -777.0, dtype=torch.float32, device=cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    o_Vn = np.full(n, -777.0, dtype=np.float32)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b,
+                       gamma, d_delta.data_ptr())
+        torch.cuda.synchronize()
+        _, o_delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma,
+                                    a, b, out=o_Vn)
+        assert np.float32(d_delta.item()) == np.float32(o_delta), (a, b)
+    H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "piecewise V'")
+    # 5 ping-pong sweeps == 5 oracle sweeps
+    d_A, d_B = d_V.clone(), torch.zeros_like(d_V)
+    eng.eval_sweeps(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n,
+                    gamma, 5, d_delta.data_ptr())
+    torch.cuda.synchronize()
+    cur = V
+    for _ in range(5):
+        cur, o_delta = chk.eval_sweep(states, acts, pol, cur, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(d_B.cpu().numpy(), cur, "5 ping-pong sweeps")
+    assert np.float32(d_delta.item()) == np.float32(o_delta)
+    # piecewise improvement
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    total = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
+                          d_changed.data_ptr())
+        total += int(d_changed.item())
+    o_pol, o_changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    assert np.array_equal(d_pol.cpu().numpy(), o_pol)
+    assert total == o_changed
+    # idempotence: improving again against the same V changes nothing
+    eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                      d_changed.data_ptr())
+    assert int(d_changed.item()) == 0
+    eng.close()
+
+
+def test_c1_full_run_matches_oracle_and_reference_counts(cuda_device):
+    """BASELINE config C1 (Pendulum 50x50, 11 torques) through the public solver API: V, policy
+    and sweep counts equal the oracle's run; the reference-text golden (glibc libm) agrees on
+    the iteration structure and to the stated tolerance."""
+    g = np.load(H.GOLDEN / "pendulum_c1_run.npz")
+    cfg = envs.CudaPIConfig(**envs.PendulumCuda.CONFIG)
+    solver = envs.PendulumCuda(envs.PendulumCuda.bins_space(50), g["actions"], cfg, device=cuda_device)
+    solver.run()
+    bins = [g["bins0"], g["bins1"]]
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    ref = H.oracle_for("pendulum").run(states, g["actions"], np.zeros(len(states), bool), lo, hi,
+                                       gshape, strides, gamma=cfg.gamma, theta=cfg.theta,
+                                       max_eval_iter=cfg.max_eval_iter, max_pi_iter=cfg.max_pi_iter)
+    assert solver.stats["eval_sweeps"] == ref["eval_sweeps"]
+    assert solver.stats["pi_iterations"] == ref["outer_iterations"]
+    assert np.array_equal(solver.policy, ref["policy"])
+    H.assert_bits_equal(solver.value_function, ref["value_function"], "C1 V")
+    # reference-text golden
+    assert np.mean(solver.policy == g["policy"]) >= 0.995
+    assert np.max(np.abs(solver.value_function - g["value_function"])) <= 2e-4 * np.max(np.abs(g["value_function"]))
+
+
+def test_c2_full_run_matches_oracle(cuda_device):
+    """BASELINE config C2: Pendulum 200x200, 21 torques, fp32, full run() on one MI355X."""
+    cls = envs.PendulumCuda
+    cfg = envs.CudaPIConfig(**cls.CONFIG)
+    solver = envs.make("pendulum", 200, device=cuda_device)
+    solver.run()
+    bins = H.env_bins("pendulum", (200, 200))
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    ref = H.oracle_for("pendulum").run(states, cls.ACTIONS, np.zeros(len(states), bool), lo, hi,
+                                       gshape, strides, gamma=cfg.gamma, theta=cfg.theta,
+                                       max_eval_iter=cfg.max_eval_iter, max_pi_iter=cfg.max_pi_iter)
+    assert solver.stats["eval_sweeps"] == ref["eval_sweeps"]
+    assert solver.stats["pi_iterations"] == ref["outer_iterations"]
+    assert np.array_equal(solver.policy, ref["policy"])
+    H.assert_bits_equal(solver.value_function, ref["value_function"], "C2 V")
+
+
+def test_full_size_c4_properties(cuda_device):
+    """BASELINE config C4 (double pendulum 80^4 x 11 actions = 40.96 M states) at full size:
+    size-independent properties + oracle spot-check of whole 256-state chunks."""
+    torch = _torch()
+    name, shape = "double_pendulum_swingup", (80, 80, 80, 80)
+    eng, bins, acts = _engine(name, shape, cuda_device)
+    n = int(np.prod(shape))
+    gamma = float(np.float32(0.999))
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    V = torch.randn(n, generator=gen, dtype=torch.float32)
+    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
+    d_V, d_pol = V.to(cuda_device), pol.to(cuda_device)
+    d_term = torch.zeros(n, dtype=torch.uint8, device=cuda_device)
+    d_Vn = torch.empty_like(d_V)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                   d_delta.data_ptr())
+    torch.cuda.synchronize()
+    # residual == max|V' - V| computed independently
+    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
+    # sharded == unsharded, bit for bit (what the multi-GPU path relies on)
+    d_Vs = torch.empty_like(d_V)
+    for r in range(4):
+        a, b = r * (n // 4), (r + 1) * (n // 4)
+        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b,
+                       gamma, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_Vs, d_Vn)
+    # linearity of the evaluation operator in V for a fixed policy: T(V + c) - T(V) = gamma*c
+    # (up to fp32 rounding of the interpolation weights, which sum to 1 within a few ulp)
+    d_Vc = torch.empty_like(d_V)
+    d_V8 = d_V + 8.0
+    eng.eval_sweep(d_V8.data_ptr(), d_Vc.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n,
+                   gamma, 0)
+    torch.cuda.synchronize()
+    assert float((d_Vc - d_Vn - gamma * 8.0).abs().max().item()) < 5e-5
+    # contraction: |T V1 - T V2|_inf <= gamma |V1 - V2|_inf (+ rounding)
+    d_V2 = d_V * 0.5
+    d_Vn2 = torch.empty_like(d_V)
+    eng.eval_sweep(d_V2.data_ptr(), d_Vn2.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
+    torch.cuda.synchronize()
+    assert float((d_Vn - d_Vn2).abs().max()) <= gamma * float((d_V - d_V2).abs().max()) + 1e-4
+    # oracle spot check: whole chunks at the start, the middle (row/plane crossings) and the end
+    chk = H.oracle_for(name)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    Vh, polh = V.numpy(), pol.numpy()
+    Vn_h = d_Vn.cpu().numpy()
+    # improve on a window, then compare both against the oracle restricted to the window
+    windows = [(0, 4096), (n // 2 - 3000, n // 2 + 3000), (n - 5000, n)]
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    for a, b in windows:
+        sub = np.arange(a, b)
+        idx = np.stack(np.unravel_index(sub, shape), axis=1)
+        st = np.stack([bins[d][idx[:, d]] for d in range(4)], axis=1).astype(np.float32)
+        # oracle on the window: states array holds only the window rows, shifted indexing
+        pad_states = np.zeros((b, 4), dtype=np.float32)
+        pad_states[a:b] = st
+        o_Vn = np.zeros(b, dtype=np.float32)
+        chk.eval_sweep(pad_states, acts, polh[:b], Vh, np.zeros(b, np.uint8), lo, hi, gshape,
+                       strides, gamma, a, b, out=o_Vn)
+        H.assert_bits_equal(Vn_h[a:b], o_Vn[a:b], f"C4 eval window [{a},{b})")
+        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
+                          d_changed.data_ptr())
+        o_pol, o_changed = chk.improve_sweep(pad_states, acts, polh[:b], Vh, np.zeros(b, np.uint8),
+                                             lo, hi, gshape, strides, gamma, a, b)
+        assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
+        assert int(d_changed.item()) == o_changed
+    eng.close()
+
+
+def test_error_paths(cuda_device):
+    eng, bins, acts = _engine("pendulum", (16, 16), cuda_device)
+    torch = _torch()
+    v = torch.zeros(256, dtype=torch.float32, device=cuda_device)
+    p = torch.zeros(256, dtype=torch.int32, device=cuda_device)
+    t = torch.zeros(256, dtype=torch.uint8, device=cuda_device)
+    with pytest.raises(_native.NativeError, match="outside"):
+        eng.eval_sweep(v.data_ptr(), v.clone().data_ptr(), p.data_ptr(), t.data_ptr(), 0, 257, 0.99)
+    with pytest.raises(_native.NativeError, match="different buffers"):
+        eng.eval_sweep(v.data_ptr(), v.data_ptr(), p.data_ptr(), t.data_ptr(), 0, 256, 0.99)
+    eng.close()
+    bad = _native.Engine(2, [16, 16], [0, 0], [1, 1], [np.linspace(0, 1, 16)] * 2, [0.0], device=0)
+    with pytest.raises(_native.NativeError, match="compil"):
+        bad.compile("__device__ void step_dynamics(float a) { this is not C }")
+    with pytest.raises(_native.NativeError, match="pi_compile has not been called"):
+        bad.eval_sweep(v.data_ptr(), v.clone().data_ptr(), p.data_ptr(), t.data_ptr(), 0, 256, 0.99)
+    bad.close()
