@@ -60,6 +60,11 @@ def lib() -> ctypes.CDLL:
     if _load_error is not None:
         raise NativeError(str(_load_error)) from _load_error
     try:
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in
+        # one process do not work ("no ROCm-capable device"), so make sure torch's copy is the
+        # one already mapped before ours is resolved: device pointers and streams handed
+        # across the C ABI then belong to the same runtime.
+        import torch  # noqa: F401
         if not LIB_PATH.exists():
             raise FileNotFoundError(
                 f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; "

@@ -68,6 +68,18 @@ def states_from_bins(bins_list):
     return np.column_stack([g.ravel() for g in grids]).astype(np.float32)
 
 
+def default_threads() -> int:
+    """Host threads the checker uses: the affinity mask, capped at 16 (a 1-GPU box's share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    env = os.environ.get("PI_ORACLE_THREADS") or os.environ.get("OMP_NUM_THREADS")
+    if env:
+        n = min(n, int(env))
+    return max(1, min(n, 16))
+
+
 class OracleLib:
     def __init__(self, path: Path, D: int):
         self.path = Path(path)
@@ -79,6 +91,11 @@ class OracleLib:
         lib.oracle_uses_libm.restype = ctypes.c_int
         assert lib.oracle_dim() == D
         self.libm = bool(lib.oracle_uses_libm())
+        self.threads = 1
+        if hasattr(lib, "oracle_set_threads"):
+            lib.oracle_set_threads.argtypes = [ctypes.c_int]
+            lib.oracle_set_threads.restype = None
+            self.set_threads(default_threads())
         lib.oracle_interp.argtypes = [ctypes.c_int64, _f32p, _f32p, _f32p, _i32p, _i32p, _i32p, _f32p]
         lib.oracle_interp.restype = None
         lib.oracle_step.argtypes = [ctypes.c_int64, _f32p, _f32p, _f32p, _f32p, _u8p]
@@ -94,6 +111,12 @@ class OracleLib:
                                    _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_int32, ctypes.c_int32, _f32p, _i64p, _i32p]
         lib.oracle_run.restype = None
+
+    def set_threads(self, n: int) -> None:
+        """OpenMP threads for the sweeps (results do not depend on it: Jacobi sweeps)."""
+        if hasattr(self._lib, "oracle_set_threads"):
+            self.threads = int(n)
+            self._lib.oracle_set_threads(int(n))
 
     # -- K1/K4/K7 ---------------------------------------------------------------
     def interp(self, pts, lo, hi, shape, strides):

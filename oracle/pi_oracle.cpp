@@ -33,6 +33,9 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifndef PI_D
 #error "build with -DPI_D=2, 4 or 6"
@@ -126,6 +129,13 @@ inline float backup(const float* s, float a, const float* V, const float* lo, co
 extern "C" {
 
 int oracle_dim(void) { return PI_D; }
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int oracle_uses_libm(void) {
 #ifdef PI_ORACLE_LIBM
     return 1;
