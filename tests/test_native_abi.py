@@ -1,0 +1,155 @@
+"""
+CPU-side checks of libpi_mi355.so: it loads, exports every symbol include/pi_mi355.h
+declares, specialises the kernel template for every env through hipRTC (no GPU needed to
+COMPILE for gfx950), and fails loudly instead of falling back.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from dynamicprogramming_amd import _native, envs
+from tests import helpers as H
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "pi_mi355.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pi_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _native.lib()
+    names = declared_symbols()
+    assert {"pi_create", "pi_compile", "pi_eval_sweep", "pi_eval_sweeps", "pi_improve_sweep",
+            "pi_destroy", "pi_last_error"} <= set(names)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in pi_mi355.h but not exported"
+        assert name in _native.SIGNATURES, f"{name} has no ctypes signature in _native.py"
+    assert lib.pi_abi_version() == _native.ABI_VERSION
+
+
+def test_no_torch_types_in_the_abi():
+    text = (ROOT / "include" / "pi_mi355.h").read_text()
+    assert "torch" not in text.lower().replace("torch-rocm tensors' data_ptr", "")
+    assert "at::" not in text and "c10::" not in text
+
+
+def _host_engine(name, shape):
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    return _native.Engine(cls._D, [len(b) for b in bins], [b.min() for b in bins],
+                          [b.max() for b in bins], bins, cls.ACTIONS, device=-1)
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_every_env_compiles_for_gfx950_without_a_gpu(name, tmp_path):
+    shape = {2: (24, 17), 4: (9, 7, 11, 5), 6: (5, 4, 6, 4, 5, 4)}[envs.ENVS[name]._D]
+    eng = _host_engine(name, shape)
+    eng.compile(envs.dynamics_source(name), cache_dir=tmp_path)
+    assert eng.info(7) == 0                       # compiled, not cached
+    objs = list(tmp_path.glob("pi_*.hsaco"))
+    assert len(objs) == 1 and objs[0].stat().st_size > 4096
+    assert objs[0].read_bytes()[:4] == b"\x7fELF"
+    eng2 = _host_engine(name, shape)
+    eng2.compile(envs.dynamics_source(name), cache_dir=tmp_path)
+    assert eng2.info(7) == 1                      # second handle: served from the cache
+    src = eng.kernel_source(envs.dynamics_source(name))
+    assert "pi_eval_sweep_kernel" in src and "step_dynamics" in src and "#define sinf pi_sinf" in src
+    eng.close()
+    eng2.close()
+
+
+def test_reference_style_plugin_string_compiles_unchanged(tmp_path):
+    """A plugin written the way the reference documents it (README 'adding an env',
+    src/cuda_policy_iteration.py:113-125): #defines, a helper __device__ function, pointer
+    outputs, bool* terminated."""
+    dyn = r'''
+    #define MY_DT 0.05f
+    __device__ float my_clip(float v, float lo, float hi) { return fmaxf(lo, fminf(hi, v)); }
+    __device__ void step_dynamics(
+        float pos, float vel, float action,
+        float* next_pos, float* next_vel,
+        float* reward, bool* terminated
+    ) {
+        vel = my_clip(vel + action * MY_DT - 0.1f * sinf(pos), -1.0f, 1.0f);
+        pos = pos + vel * MY_DT;
+        *next_pos = pos; *next_vel = vel;
+        *reward = -fabsf(pos);
+        *terminated = (pos > 2.0f) || (pos < -2.0f);
+    }
+    '''
+    bins = [np.linspace(-2, 2, 21, dtype=np.float32), np.linspace(-1, 1, 11, dtype=np.float32)]
+    eng = _native.Engine(2, [21, 11], [-2, -1], [2, 1], bins, [-1.0, 0.0, 1.0], device=-1)
+    eng.compile(dyn, cache_dir=tmp_path)
+    eng.close()
+
+
+def test_compile_error_is_reported_not_swallowed(tmp_path):
+    eng = _host_engine("pendulum", (8, 8))
+    with pytest.raises(_native.NativeError) as exc:
+        eng.compile("__device__ void step_dynamics(float a) { not valid C; }", cache_dir=tmp_path)
+    assert "error" in str(exc.value).lower()
+    assert not list(tmp_path.glob("*.hsaco"))
+    eng.close()
+
+
+def test_argument_validation():
+    bins = [np.linspace(0, 1, 4, dtype=np.float32)] * 3
+    with pytest.raises(_native.NativeError, match="D must be"):
+        _native.Engine(3, [4, 4, 4], [0] * 3, [1] * 3, bins, [0.0], device=-1)
+    with pytest.raises(_native.NativeError, match="at least 2 bins"):
+        _native.Engine(2, [1, 4], [0, 0], [1, 1], [np.zeros(1, np.float32), bins[0]], [0.0], device=-1)
+    with pytest.raises(_native.NativeError, match="2\\^31"):
+        big = [np.linspace(0, 1, 40, dtype=np.float32)] * 6
+        _native.Engine(6, [40] * 6, [0] * 6, [1] * 6, big, [0.0], device=-1)
+    eng = _host_engine("pendulum", (8, 8))
+    with pytest.raises(_native.NativeError, match="host-only"):
+        eng.eval_sweep(1, 2, 3, 4, 0, 64, 0.9)
+    eng.close()
+
+
+def test_no_gpu_means_runtime_error_not_fallback():
+    """Without a GPU the product refuses to construct a solver (reference :71-75 raises for a
+    missing CuPy); it must not quietly compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dynamicprogramming_amd import solver
+    assert solver.GPU_AVAILABLE is False
+    with pytest.raises(RuntimeError, match="GPU"):
+        envs.make("pendulum", 16)
+
+
+def test_product_code_never_imports_the_oracle():
+    for sub in ("dynamicprogramming_amd", "src", "runners", "utils"):
+        for path in (ROOT / sub).rglob("*.py"):
+            text = path.read_text()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), path
+            assert "pi_oracle" not in text and "import_module(\"oracle" not in text, path
+    for path in (ROOT / "dynamicprogramming_amd" / "csrc").glob("*"):
+        if path.is_file():
+            text = path.read_text()
+            assert not re.search(r'#include\s+"[^"]*oracle', text), path
+            if path.name == "Makefile":
+                assert "oracle" not in text, path
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_load_error", None)
+    monkeypatch.setattr(_native, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_native.NativeError, match="not found"):
+        _native.lib()
+    assert _native.available() is False
+    monkeypatch.setattr(_native, "_load_error", None)
+
+
+def test_ctypes_pointer_sizes():
+    assert ctypes.sizeof(ctypes.c_void_p) == 8

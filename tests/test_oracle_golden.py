@@ -1,0 +1,191 @@
+"""
+CPU tests of the oracle itself (no GPU): oracle/pi_oracle.cpp + this repo's env plugin
+strings against (a) the vectors generated from the reference's own kernel text
+(tests/golden/*.npz, bit for bit, libm arithmetic mode), (b) the two result archives the
+reference commits (end-to-end, stated tolerance) and (c) known-answer properties.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+from dynamicprogramming_amd import envs
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_dynamics_equal_reference_text(name):
+    g = H.golden(name)
+    nxt, rew, term = H.oracle_for(name, libm=True).step(g["step_states"], g["step_actions"])
+    H.assert_bits_equal(nxt, g["step_next"], f"{name} next")
+    H.assert_bits_equal(rew, g["step_reward"], f"{name} reward")
+    assert np.array_equal(term, g["step_term"])
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+@pytest.mark.parametrize("gi", [0, 1])
+def test_interp_and_sweeps_equal_reference_text(name, gi):
+    g = H.golden(name)
+    shape = g[f"g{gi}_shape"]
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    chk = H.oracle_for(name, libm=True)
+    idx, w = chk.interp(g[f"g{gi}_pts"], lo, hi, gshape, strides)
+    assert np.array_equal(idx, g[f"g{gi}_idx"])
+    H.assert_bits_equal(w, g[f"g{gi}_w"], "weights")
+    acts, gamma = g["actions"], float(g["gamma"])
+    V, pol, term = g[f"g{gi}_V"], g[f"g{gi}_policy"], g[f"g{gi}_term"]
+    Vn, delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(Vn, g[f"g{gi}_V_next"], "V'")
+    assert np.float32(delta) == g[f"g{gi}_delta"]
+    pol_n, changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    assert np.array_equal(pol_n, g[f"g{gi}_policy_next"])
+    assert changed == int(g[f"g{gi}_changed"])
+    # terminal states: V copied, policy untouched
+    assert np.array_equal(Vn[term], V[term]) and np.array_equal(pol_n[term], pol[term])
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_product_arithmetic_close_to_libm(name):
+    """pi_math mode (the product's sinf/cosf) vs glibc mode: same indices, ulp-level values."""
+    g = H.golden(name)
+    nxt, rew, term = H.oracle_for(name).step(g["step_states"], g["step_actions"])
+    np.testing.assert_allclose(nxt, g["step_next"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(rew, g["step_reward"], rtol=2e-4, atol=2e-4)
+    shape = g["g1_shape"]
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    chk = H.oracle_for(name)
+    Vn, _ = chk.eval_sweep(states, g["actions"], g["g1_policy"], g["g1_V"], g["g1_term"], lo, hi,
+                           gshape, strides, float(g["gamma"]))
+    gV = g["g1_V_next"]
+    assert np.all(np.abs(Vn - gV) <= 2e-4 * np.maximum(1.0, np.abs(gV)))
+    pol_n, _ = chk.improve_sweep(states, g["actions"], g["g1_policy"], g["g1_V"], g["g1_term"], lo,
+                                 hi, gshape, strides, float(g["gamma"]))
+    firm = g["g1_q_gap"] > 1e-3
+    assert np.array_equal(pol_n[firm], g["g1_policy_next"][firm])
+
+
+def test_c1_run_reproduces_reference_text_run():
+    """BASELINE config C1: 14 outer iterations / 10 139 evaluation sweeps."""
+    g = np.load(H.GOLDEN / "pendulum_c1_run.npz")
+    bins = [g["bins0"], g["bins1"]]
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    kw = dict(gamma=float(g["gamma"]), theta=float(g["theta"]), max_eval_iter=int(g["max_eval_iter"]),
+              max_pi_iter=int(g["max_pi_iter"]))
+    res = H.oracle_for("pendulum", libm=True).run(states, g["actions"], np.zeros(len(states), bool),
+                                                  lo, hi, gshape, strides, **kw)
+    assert res["outer_iterations"] == int(g["outer_iterations"]) == 14
+    assert res["eval_sweeps"] == int(g["eval_sweeps"]) == 10139
+    assert np.array_equal(res["sweeps_per_iter"], g["sweeps_per_iter"])
+    assert np.array_equal(res["policy"], g["policy"])
+    H.assert_bits_equal(res["value_function"], g["value_function"], "C1 V")
+    # product arithmetic: same iteration structure, values to tolerance
+    res2 = H.oracle_for("pendulum").run(states, g["actions"], np.zeros(len(states), bool), lo, hi,
+                                        gshape, strides, **kw)
+    assert res2["outer_iterations"] == 14
+    assert np.mean(res2["policy"] == g["policy"]) >= 0.995
+    assert np.max(np.abs(res2["value_function"] - g["value_function"])) <= 2e-4 * np.max(np.abs(g["value_function"]))
+
+
+@pytest.mark.parametrize("name", ["mountain_car", "continuous_mountain_car"])
+def test_full_run_against_reference_committed_results(name):
+    """The only reference-PRODUCED end-to-end numbers (runners/results/*.npz, RTX 3090 +
+    libdevice): policy agreement >= 99.5 %, |dV| <= 2e-4 on >= 99.5 % of the states."""
+    ref = np.load(H.GOLDEN / "reference_results.npz")
+    cls = envs.ENVS[name]
+    shape = tuple(int(x) for x in ref[f"{name}_grid_shape"])
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    assert np.array_equal(lo, ref[f"{name}_bounds_low"]) and np.array_equal(hi, ref[f"{name}_bounds_high"])
+    assert np.array_equal(np.asarray(cls.ACTIONS, np.float32), ref[f"{name}_action_space"])
+    states = oracle.states_from_bins(bins)
+    term, tval = H.terminal_mask(name, states)
+    cfg = cls.CONFIG
+    for libm in (True, False):
+        res = H.oracle_for(name, libm=libm).run(states, cls.ACTIONS, term, lo, hi, gshape, strides,
+                                                gamma=cfg["gamma"], theta=cfg["theta"],
+                                                max_eval_iter=cfg["max_eval_iter"],
+                                                max_pi_iter=cfg["max_pi_iter"], terminal_value=tval)
+        agree = np.mean(res["policy"] == ref[f"{name}_policy"])
+        dv = np.abs(res["value_function"] - ref[f"{name}_value_function"])
+        assert agree >= 0.995, (name, libm, agree)
+        assert np.mean(dv <= 2e-4) >= 0.995, (name, libm, float(np.mean(dv <= 2e-4)))
+        assert res["stable"]
+
+
+# ── known-answer properties ────────────────────────────────────────────────────────
+@pytest.mark.parametrize("D", [2, 4, 6])
+def test_interpolation_properties(D):
+    name = {2: "pendulum", 4: "cartpole", 6: "double_cartpole"}[D]
+    shape = {2: (11, 7), 4: (5, 4, 6, 3), 6: (3, 4, 2, 5, 3, 2)}[D]
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    rng = np.random.default_rng(D)
+    pts = H.sample_states(rng, bins, 4000)
+    idx, w = H.oracle_for(name).interp(pts, lo, hi, gshape, strides)
+    n = int(np.prod(shape))
+    assert idx.min() >= 0 and idx.max() < n
+    assert np.all(w >= 0.0)
+    np.testing.assert_allclose(w.sum(axis=1, dtype=np.float64), 1.0, atol=4e-7 * (1 << D))
+    # exact grid nodes interpolate to themselves: one weight 1, rest 0, at the node's index
+    nodes = oracle.states_from_bins(bins)
+    idx_n, w_n = H.oracle_for(name).interp(nodes, lo, hi, gshape, strides)
+    V = rng.standard_normal(n).astype(np.float32)
+    approx = (w_n.astype(np.float64) * V[idx_n]).sum(axis=1)
+    np.testing.assert_allclose(approx, V, atol=5e-5)
+    # multilinear functions are reproduced (interpolation is exact for them up to rounding)
+    coef = rng.standard_normal(D)
+    f = nodes.astype(np.float64) @ coef
+    inside = np.all((pts >= lo) & (pts <= hi), axis=1)
+    got = (w[inside].astype(np.float64) * f[idx[inside]]).sum(axis=1)
+    np.testing.assert_allclose(got, pts[inside].astype(np.float64) @ coef, atol=2e-4)
+
+
+def test_absorbing_one_cell_mdp_value():
+    """V* of a state that returns to itself with reward r is r / (1 - gamma)."""
+    dyn = r'''
+    __device__ void step_dynamics(float a, float b, float u, float* na, float* nb,
+                                  float* r, bool* t) { *na = a; *nb = b; *r = 2.0f; *t = false; }
+    '''
+    chk = oracle.build(2, dyn)
+    bins = [np.linspace(0, 1, 3, dtype=np.float32)] * 2
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    res = chk.run(states, np.array([0.0], np.float32), np.zeros(9, bool), lo, hi, gshape, strides,
+                  gamma=0.9, theta=1e-6, max_eval_iter=1000, max_pi_iter=3)
+    np.testing.assert_allclose(res["value_function"], 2.0 / (1 - 0.9), rtol=1e-4)
+    assert res["stable"] and res["outer_iterations"] == 1
+
+
+def test_terminated_transition_gives_reward_only_and_contraction():
+    name = "cartpole"
+    bins = H.env_bins(name, (6, 5, 7, 5))
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    term, _ = H.terminal_mask(name, states)
+    chk = H.oracle_for(name)
+    rng = np.random.default_rng(1)
+    acts = envs.ENVS[name].ACTIONS
+    pol = rng.integers(0, 2, len(states)).astype(np.int32)
+    V1 = rng.standard_normal(len(states)).astype(np.float32)
+    V2 = rng.standard_normal(len(states)).astype(np.float32)
+    g = 0.99
+    T1, _ = chk.eval_sweep(states, acts, pol, V1, term, lo, hi, gshape, strides, g)
+    T2, _ = chk.eval_sweep(states, acts, pol, V2, term, lo, hi, gshape, strides, g)
+    live = ~term
+    assert np.max(np.abs(T1 - T2)[live]) <= g * np.max(np.abs(V1 - V2)) + 1e-5
+    _, rew, done = chk.step(states, acts[pol])
+    sel = live & done
+    assert sel.any()
+    H.assert_bits_equal(T1[sel], (rew[sel] + np.float32(g) * np.float32(0.0)).astype(np.float32), "Q = r")
+
+
+def test_residual_checked_only_every_25_sweeps():
+    """An evaluation takes 1, 26, 51, ... sweeps (SURVEY.md §3.1 note)."""
+    g = np.load(H.GOLDEN / "pendulum_c1_run.npz")
+    assert all(int(s) % 25 == 1 or int(s) == int(g["max_eval_iter"]) for s in g["sweeps_per_iter"])
