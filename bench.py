@@ -90,6 +90,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bins", type=int, default=BINS, help="grid points per dimension (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transition-cache", action="store_true",
+                    help="recompute the dynamics in every evaluation sweep (reference behaviour)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22)
     args = ap.parse_args()
 
@@ -108,7 +110,8 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     cls = envs.ENVS[ENV]
-    solver = envs.make(ENV, args.bins, device=dev)
+    cfg = envs.CudaPIConfig(**cls.CONFIG, cache_transitions=not args.no_transition_cache)
+    solver = envs.make(ENV, args.bins, config=cfg, device=dev)
     n, nA, D = solver.n_states, solver.n_actions, cls._D
     gamma = float(np.float32(solver.config.gamma))
 
@@ -121,17 +124,23 @@ def main() -> None:
     solver.d_policy[:n].copy_(P0)
     del V0, P0
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    cached = getattr(solver._backend, "_cache", None) is not None
 
     def step(k=None):
+        # One policy evaluation of EVAL_PER_STEP sweeps (sweep 0 also records the transitions
+        # when the cache is on; the rest replay them), then one improvement.
         if k is not None:
             ev[k][0].record()
-        solver._evaluation_sweeps(EVAL_PER_STEP, gamma)
+        solver._evaluation_sweeps(1, gamma)
         if k is not None:
             ev[k][1].record()
-        solver._improvement_sweep(gamma)
+        solver._evaluation_sweeps(EVAL_PER_STEP - 1, gamma)
         if k is not None:
             ev[k][2].record()
+        solver._improvement_sweep(gamma)
+        if k is not None:
+            ev[k][3].record()
 
     for _ in range(args.warmup):
         step()
@@ -152,8 +161,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    eval_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) / EVAL_PER_STEP
-    improve_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / IMPROVE_PER_STEP
+    first_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / (EVAL_PER_STEP - 1)
+    improve_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) / IMPROVE_PER_STEP
     # sanity: the sweeps really ran (residual and change count of the last step)
     last_delta = float(solver._d_delta.item())
     last_changed = int(solver._d_changed.item())
@@ -162,8 +172,27 @@ def main() -> None:
     value = backups_per_step * args.steps / elapsed
     states_per_launch = solver._s_end - solver._s_begin
     bytes_eval = algorithmic_bytes_eval(D)
-    achieved = bytes_eval * states_per_launch / (eval_ms * 1e-3) / 1e9
     bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
+
+    def roof(kernel, bytes_per_backup, backups, ms):
+        ach = bytes_per_backup * backups / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_backup": bytes_per_backup, "backups_per_launch": backups,
+                "avg_launch_ms": ms}
+
+    kernels = {
+        "first_eval_sweep": roof("pi_eval_build_kernel" if cached else "pi_eval_sweep_kernel",
+                                 bytes_eval, states_per_launch, first_ms),
+        "other_eval_sweeps": roof("pi_eval_replay_kernel" if cached else "pi_eval_sweep_kernel",
+                                  bytes_eval, states_per_launch, rest_ms),
+        "improve_sweep": roof("pi_improve_sweep_kernel", bytes_improve, states_per_launch * nA,
+                              improve_ms),
+    }
+    share = {"first_eval_sweep": first_ms, "other_eval_sweeps": rest_ms * (EVAL_PER_STEP - 1),
+             "improve_sweep": improve_ms * IMPROVE_PER_STEP}
+    dominant = max(share, key=share.get)
+    eng = solver._backend.engine
     out = {
         "metric": "state-action Bellman backups/sec",
         "value": value,
@@ -181,19 +210,16 @@ def main() -> None:
                                f"({n} states) x {nA} actions, gamma=0.999; step = {EVAL_PER_STEP} "
                                f"eval sweeps + {IMPROVE_PER_STEP} improve sweep = {backups_per_step} backups",
                    "states": n, "actions": nA, "eval_sweeps_per_step": EVAL_PER_STEP,
-                   "improve_sweeps_per_step": IMPROVE_PER_STEP,
+                   "improve_sweeps_per_step": IMPROVE_PER_STEP, "transition_cache": cached,
                    "parallelism": f"state-range shards x{world}" + (", RCCL all-gather of V per eval sweep" if world > 1 else "")},
-        "roofline": {"bound": "hbm", "kernel": "pi_eval_sweep_kernel",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_per_backup": bytes_eval, "backups_per_launch": states_per_launch,
-                     "avg_launch_ms": eval_ms},
-        "eval_backups_per_s": states_per_launch * world / (eval_ms * 1e-3),
+        "roofline": kernels[dominant],
+        "kernels": kernels,
+        "time_share_ms": share,
+        "eval_backups_per_s": states_per_launch * world * EVAL_PER_STEP / ((first_ms + rest_ms * (EVAL_PER_STEP - 1)) * 1e-3),
         "improve_backups_per_s": states_per_launch * world * nA / (improve_ms * 1e-3),
-        "improve_roofline": {"achieved": bytes_improve * states_per_launch * nA / (improve_ms * 1e-3) / 1e9,
-                             "bytes_per_backup": bytes_improve, "avg_launch_ms": improve_ms},
         "check": {"last_residual": last_delta, "last_changed": last_changed,
-                  "vgpr_eval": solver._backend.engine.info(4), "vgpr_improve": solver._backend.engine.info(5)},
+                  "vgpr_eval": eng.info(4), "vgpr_improve": eng.info(5), "vgpr_replay": eng.info(8),
+                  "replay_states_per_thread": eng.info(9)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_sample)

@@ -36,6 +36,10 @@ SIGNATURES = {
                                      ctypes.c_float, _vp, _vp]),
     "pi_eval_sweeps": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, ctypes.c_int, _vp, _vp]),
+    "pi_transition_cache_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int64, ctypes.c_int64]),
+    "pi_eval_sweeps_cached": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp,
+                                             ctypes.c_size_t, _vp, _vp]),
     "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, _vp, _vp]),
     "pi_probe_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
@@ -154,6 +158,15 @@ class Engine:
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta=0, stream=0):
         _check(lib().pi_eval_sweeps(self._h, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps,
                                     d_delta or None, stream or None), "pi_eval_sweeps")
+
+    def transition_cache_bytes(self, s_begin, s_end) -> int:
+        return int(lib().pi_transition_cache_bytes(self._h, s_begin, s_end))
+
+    def eval_sweeps_cached(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, rebuild,
+                           cache, cache_bytes, d_delta=0, stream=0):
+        _check(lib().pi_eval_sweeps_cached(self._h, Va, Vb, policy, term, s_begin, s_end, gamma,
+                                           n_sweeps, int(bool(rebuild)), cache, cache_bytes,
+                                           d_delta or None, stream or None), "pi_eval_sweeps_cached")
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
         _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,

@@ -64,6 +64,9 @@ class CudaPIConfig:
     max_eval_iter: int = 10_000   # sweeps per policy evaluation, at most
     max_pi_iter: int = 50         # outer evaluate/improve iterations, at most
     log_interval: int = 100       # log the residual every N sweeps (at check points)
+    # MI355X extension (results are bit-identical either way): record each state's transition
+    # on the first sweep of a policy evaluation and replay it on the following sweeps.
+    cache_transitions: bool = True
 
 
 class HipSweepBackend:
@@ -87,10 +90,29 @@ class HipSweepBackend:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
-        self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
-                                s_begin, s_end, gamma, n_sweeps,
-                                0 if d_delta is None else d_delta.data_ptr(), self._stream())
+    def enable_transition_cache(self, s_begin: int, s_end: int) -> bool:
+        """Reserve the record workspace for one state range ((2 + D) * 4 B per state)."""
+        need = self.engine.transition_cache_bytes(s_begin, s_end)
+        if need == 0:
+            return False
+        try:
+            self._cache = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        except RuntimeError as exc:          # out of HBM: keep recomputing the dynamics
+            logger.warning(f"transition cache disabled ({need / 2**30:.1f} GiB not available): {exc}")
+            self._cache = None
+        return self._cache is not None
+
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta,
+                    rebuild=True):
+        delta_ptr = 0 if d_delta is None else d_delta.data_ptr()
+        if getattr(self, "_cache", None) is not None:
+            self.engine.eval_sweeps_cached(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(),
+                                           term.data_ptr(), s_begin, s_end, gamma, n_sweeps, rebuild,
+                                           self._cache.data_ptr(), self._cache.numel(), delta_ptr,
+                                           self._stream())
+        else:
+            self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
+                                    s_begin, s_end, gamma, n_sweeps, delta_ptr, self._stream())
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), term.data_ptr(), s_begin, s_end,
@@ -98,6 +120,7 @@ class HipSweepBackend:
                                   self._stream())
 
     def close(self):
+        self._cache = None
         self.engine.close()
 
 
@@ -209,6 +232,9 @@ class _CudaPolicyIterationBase(abc.ABC):
                                 device=self._device_arg)
         dev = self._backend.device
         self._init_sharding()
+        self._records_stale = True
+        if getattr(self.config, "cache_transitions", False) and hasattr(self._backend, "enable_transition_cache"):
+            self._backend.enable_transition_cache(self._s_begin, self._s_end)
 
         n, n_pad = self.n_states, self._n_pad
         self.d_policy = torch.zeros(n_pad, dtype=torch.int32, device=dev)
@@ -275,10 +301,11 @@ class _CudaPolicyIterationBase(abc.ABC):
     def _evaluation_sweeps(self, n: int, gamma: float) -> None:
         """n Jacobi sweeps under the current policy; afterwards ``d_value_function`` is the
         newest iterate and ``_d_delta`` holds the residual of the last sweep (max over ranks)."""
+        rebuild, self._records_stale = self._records_stale, False
         if self._world == 1:
             self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
                                       self.d_policy, self.d_terminal_mask, self._s_begin,
-                                      self._s_end, gamma, n, self._d_delta)
+                                      self._s_end, gamma, n, self._d_delta, rebuild=rebuild)
             if n & 1:
                 self.d_value_function, self.d_new_value_function = (
                     self.d_new_value_function, self.d_value_function)
@@ -286,7 +313,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         for k in range(n):
             self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
                                       self.d_policy, self.d_terminal_mask, self._s_begin,
-                                      self._s_end, gamma, 1, self._d_delta if k == n - 1 else None)
+                                      self._s_end, gamma, 1, self._d_delta if k == n - 1 else None,
+                                      rebuild=rebuild and k == 0)
             self._all_gather_shards(self.d_new_value_function)
             self.d_value_function, self.d_new_value_function = (
                 self.d_new_value_function, self.d_value_function)
@@ -297,6 +325,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         over ranks)."""
         self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
                                     self._s_begin, self._s_end, gamma, self._d_changed)
+        self._records_stale = True            # the policy may have changed
         if self._world > 1:
             self._all_reduce_scalar(self._d_changed, "SUM")
 
@@ -309,6 +338,9 @@ class _CudaPolicyIterationBase(abc.ABC):
         t0 = time.perf_counter()
         i = 0
         sweeps = 0
+        # d_policy / d_terminal_mask are public attributes a caller may have edited since the
+        # last evaluation: never trust transition records across calls.
+        self._records_stale = True
         while i < cfg.max_eval_iter:
             check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
             check = min(check, cfg.max_eval_iter - 1)

@@ -98,6 +98,25 @@ int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
                    int n_sweeps, float* d_delta, void* stream);
 
 /*
+ * Policy evaluation with TRANSITION RECORDS (MI355X-first; no counterpart in the reference,
+ * same results bit for bit).  Between two policy improvements the policy is fixed, so the
+ * transition of every state — reward, interpolation cell, fractional offsets — is the same in
+ * every sweep of policy_evaluation's loop (:305-331).  With rebuild != 0 the first sweep runs
+ * step_dynamics as usual and also writes (2 + D) * 4 bytes per state into `cache`; every
+ * later sweep (and later calls with rebuild = 0) replays those records and only gathers V.
+ *   cache, cache_bytes : caller-owned device workspace, 16-byte aligned, at least
+ *                        pi_transition_cache_bytes(h, s_begin, s_end) bytes.
+ *   rebuild            : must be non-zero on the first call after `policy`, `term`, the
+ *                        range or the cache buffer changed (the library checks the last two).
+ * Ping-pong and d_delta semantics as pi_eval_sweeps.  Va / Vb must be 16-byte aligned.
+ */
+size_t pi_transition_cache_bytes(pi_handle* h, int64_t s_begin, int64_t s_end);
+int pi_eval_sweeps_cached(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
+                          const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,
+                          int n_sweeps, int rebuild, void* cache, size_t cache_bytes,
+                          float* d_delta, void* stream);
+
+/*
  * Greedy improvement over [s_begin, s_end): policy[s] = argmax_a Q(s, a), first
  * maximum wins, terminal states untouched.  Replaces the improve_kernel launch
  * (:342-352, :750-760, :1182-1192) AND `old = policy.copy(); all(policy == old)`
@@ -122,7 +141,8 @@ int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, 
 
 /* Introspection: 0 n_states, 1 n_actions, 2 D, 3 workgroups per launch,
  * 4 VGPRs of the eval kernel, 5 VGPRs of the improve kernel, 6 compute units,
- * 7 = 1 if the last pi_compile was served from the cache. */
+ * 7 = 1 if the last pi_compile was served from the cache, 8 VGPRs of the replay kernel,
+ * 9 states per thread of the replay kernel. */
 int64_t pi_info(pi_handle* h, int what);
 
 #ifdef __cplusplus

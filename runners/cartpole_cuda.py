@@ -1,0 +1,16 @@
+"""
+runners/cartpole_cuda.py — train CartPole-v1 balance; reference runner runners/cartpole_cuda.py.
+
+    python runners/cartpole_cuda.py [--bins N] [--retrain] [--save-path results/cartpole_cuda_policy.npz]
+
+The env plugin (dynamics string, grid, actions, solver settings) is
+``dynamicprogramming_amd.envs.CartPoleCuda``; this script is only the entry point.
+"""
+from _cli import main, train  # noqa: F401  (runners/ is on sys.path when run as a script)
+
+from dynamicprogramming_amd.envs import CartPoleCuda  # noqa: E402,F401  re-exported for `from runners...`
+
+ENV = "cartpole"
+
+if __name__ == "__main__":
+    main(ENV, "results/cartpole_cuda_policy.npz")

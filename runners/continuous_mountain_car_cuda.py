@@ -1,0 +1,16 @@
+"""
+runners/continuous_mountain_car_cuda.py — train MountainCarContinuous-v0; reference runner runners/continuous_mountain_car_cuda.py.
+
+    python runners/continuous_mountain_car_cuda.py [--bins N] [--retrain] [--save-path results/continuous_mountain_car_cuda_policy.npz]
+
+The env plugin (dynamics string, grid, actions, solver settings) is
+``dynamicprogramming_amd.envs.ContinuousMountainCarCuda``; this script is only the entry point.
+"""
+from _cli import main, train  # noqa: F401  (runners/ is on sys.path when run as a script)
+
+from dynamicprogramming_amd.envs import ContinuousMountainCarCuda  # noqa: E402,F401  re-exported for `from runners...`
+
+ENV = "continuous_mountain_car"
+
+if __name__ == "__main__":
+    main(ENV, "results/continuous_mountain_car_cuda_policy.npz")

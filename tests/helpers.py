@@ -104,7 +104,8 @@ class OracleSweepBackend:
         self.n = len(self.states)
         self.calls = {"eval": 0, "improve": 0}
 
-    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta,
+                    rebuild=True):
         n = self.n
         for i in range(n_sweeps):
             src, dst = (Vb, Va) if (i & 1) else (Va, Vb)

@@ -323,3 +323,96 @@ def test_error_paths(cuda_device):
     with pytest.raises(_native.NativeError, match="pi_compile has not been called"):
         bad.eval_sweep(v.data_ptr(), v.clone().data_ptr(), p.data_ptr(), t.data_ptr(), 0, 256, 0.99)
     bad.close()
+
+
+# ── transition records (pi_eval_sweeps_cached) ─────────────────────────────────────────
+def _cached_case(name, shape, dev, seed, spt, monkeypatch):
+    monkeypatch.setenv("PI_MI355_SPT", str(spt))
+    eng, acts, meta, states, term, V, pol = _sweep_case(name, shape, dev, seed)
+    assert eng.info(9) == spt
+    return eng, acts, meta, states, term, V, pol
+
+
+@pytest.mark.parametrize("spt", [1, 2, 4])
+@pytest.mark.parametrize("name,shape", [("pendulum", (33, 29)), ("mountain_car", (40, 23)),
+                                         ("cartpole", (9, 7, 11, 5)),
+                                         ("double_pendulum_swingup", (12, 11, 13, 10)),
+                                         ("overhead_crane", (9, 7, 9, 7)),
+                                         ("double_cartpole", (5, 4, 6, 4, 5, 4))])
+def test_cached_evaluation_is_bit_identical(name, shape, spt, cuda_device, monkeypatch):
+    """Recording the transitions on sweep 0 and replaying them gives exactly the V of
+    recomputing the dynamics every sweep (oracle), for full ranges, ragged shard ranges that
+    start/end off the 4-state alignment, terminal nodes and terminating transitions."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _cached_case(
+        name, shape, cuda_device, 11, spt, monkeypatch)
+    n = len(V)
+    gamma = float(np.float32(envs.ENVS[name].CONFIG["gamma"]))
+    chk = H.oracle_for(name)
+    d_pol = _dev(pol, cuda_device)
+    d_term = _dev(term.astype(np.uint8), cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    for a, b in [(0, n), (1, n - 2), (n // 3 + 1, 2 * n // 3 + 3), (5, 6), (n - 3, n)]:
+        need = eng.transition_cache_bytes(a, b)
+        assert need >= (b - a) * (2 + len(shape)) * 4
+        cache = torch.empty(need, dtype=torch.uint8, device=cuda_device)
+        d_A, d_B = _dev(V, cuda_device), torch.full((n,), -5.0, dtype=torch.float32, device=cuda_device)
+        with pytest.raises(_native.NativeError, match="rebuild"):
+            eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
+                                   a, b, gamma, 1, False, cache.data_ptr(), need, d_delta.data_ptr())
+        eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
+                               a, b, gamma, 4, True, cache.data_ptr(), need, d_delta.data_ptr())
+        torch.cuda.synchronize()
+        # oracle: 4 sweeps restricted to [a, b); outside the range both buffers keep their values
+        oA, oB = V.copy(), np.full(n, -5.0, dtype=np.float32)
+        for i in range(4):
+            src, dst = (oB, oA) if i & 1 else (oA, oB)
+            _, o_delta = chk.eval_sweep(states, acts, pol, src, term, lo, hi, gshape, strides, gamma,
+                                        a, b, out=dst)
+        H.assert_bits_equal(d_A.cpu().numpy(), oA, f"{name} [{a},{b}) buffer A")
+        H.assert_bits_equal(d_B.cpu().numpy(), oB, f"{name} [{a},{b}) buffer B")
+        assert np.float32(d_delta.item()) == np.float32(o_delta)
+        # continue without rebuilding: 3 more sweeps replay the same records
+        eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
+                               a, b, gamma, 3, False, cache.data_ptr(), need, d_delta.data_ptr())
+        torch.cuda.synchronize()
+        for i in range(3):
+            src, dst = (oB, oA) if i & 1 else (oA, oB)
+            _, o_delta = chk.eval_sweep(states, acts, pol, src, term, lo, hi, gshape, strides, gamma,
+                                        a, b, out=dst)
+        H.assert_bits_equal(d_A.cpu().numpy(), oA, "A after replay-only call")
+        H.assert_bits_equal(d_B.cpu().numpy(), oB, "B after replay-only call")
+        assert np.float32(d_delta.item()) == np.float32(o_delta)
+        with pytest.raises(_native.NativeError, match="too small"):
+            eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
+                                   a, b, gamma, 1, True, cache.data_ptr(), need - 16, 0)
+    eng.close()
+
+
+def test_solver_with_and_without_transition_cache_agree(cuda_device):
+    """Full run() on a 4-D problem with terminal states, cache on vs off: identical V, policy and
+    sweep counts (and both equal the oracle's run)."""
+    name, shape = "cartpole", (12, 10, 14, 10)
+    cls = envs.ENVS[name]
+    res = []
+    for cache in (True, False):
+        cfg = envs.CudaPIConfig(**{**cls.CONFIG, "max_pi_iter": 6, "max_eval_iter": 400},
+                                cache_transitions=cache)
+        s = cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device)
+        assert (getattr(s._backend, "_cache", None) is not None) == cache
+        s.run()
+        res.append(s)
+    assert res[0].stats["sweeps_per_iter"] == res[1].stats["sweeps_per_iter"]
+    assert np.array_equal(res[0].policy, res[1].policy)
+    H.assert_bits_equal(res[0].value_function, res[1].value_function, "cache on/off")
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    term, tval = H.terminal_mask(name, states)
+    cfg = res[0].config
+    ref = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, gamma=cfg.gamma,
+                                 theta=cfg.theta, max_eval_iter=cfg.max_eval_iter,
+                                 max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
+    assert res[0].stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
+    assert np.array_equal(res[0].policy, ref["policy"])
+    H.assert_bits_equal(res[0].value_function, ref["value_function"], "vs oracle")

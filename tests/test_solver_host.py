@@ -124,5 +124,7 @@ def test_save_load_schema(tmp_path):
 def test_reference_import_path():
     import src.cuda_policy_iteration as m
     assert m.CudaPolicyIteration4D is envs.CudaPolicyIteration4D and hasattr(m, "GPU_AVAILABLE")
-    assert m.CudaPIConfig().__dict__ == dict(gamma=0.99, theta=1e-4, max_eval_iter=10_000,
-                                             max_pi_iter=50, log_interval=100)
+    ref_fields = dict(gamma=0.99, theta=1e-4, max_eval_iter=10_000, max_pi_iter=50, log_interval=100)
+    cfg = m.CudaPIConfig()
+    assert {k: getattr(cfg, k) for k in ref_fields} == ref_fields          # reference :36-43
+    assert list(cfg.__dict__)[:5] == list(ref_fields)                      # same positional order
