@@ -49,11 +49,11 @@ def algorithmic_bytes_eval(D: int) -> int:
     return 4 * (1 << D) + 4 * D + 9          # 89 B for D = 4
 
 
-def cpu_baseline(bins: int, sample_states: int, seed: int = 0) -> dict:
+def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict:
     """Oracle timed on host cores over states [0, sample) of the same grid / V / policy."""
     import oracle
     from dynamicprogramming_amd import envs
-    cls = envs.ENVS[ENV]
+    cls = envs.ENVS[env]
     tables = [np.asarray(b, np.float32) for b in cls.bins_space(bins).values()]
     lo, hi, shape, strides = oracle.grid_metadata(tables)
     n = int(np.prod(shape))
@@ -64,7 +64,7 @@ def cpu_baseline(bins: int, sample_states: int, seed: int = 0) -> dict:
     V = rng.standard_normal(n).astype(np.float32)
     pol = rng.integers(0, len(cls.ACTIONS), size=m).astype(np.int32)
     term = np.zeros(m, dtype=np.uint8)
-    chk = oracle.build(cls._D, envs.dynamics_source(ENV))
+    chk = oracle.build(cls._D, envs.dynamics_source(env))
     gamma = np.float32(cls.CONFIG["gamma"])
     out = np.zeros(m, dtype=np.float32)
     for _ in range(2):   # warm the OpenMP team and the caches before timing
@@ -80,7 +80,7 @@ def cpu_baseline(bins: int, sample_states: int, seed: int = 0) -> dict:
     threads = chk.threads
     return {"value": backups / dt, "unit": "backups/s", "cores": threads, "kind": "port",
             "sample": f"one step (10 eval + 1 improve sweeps) over states [0, {m}) of the same "
-                      f"{bins}^4 grid, oracle/pi_oracle.cpp with OpenMP, {dt:.1f} s wall"}
+                      f"{bins}^{cls._D} grid, oracle/pi_oracle.cpp with OpenMP, {dt:.1f} s wall"}
 
 
 def main() -> None:
@@ -88,10 +88,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bins", type=int, default=BINS, help="grid points per dimension (default: the BASELINE config)")
+    ap.add_argument("--bins", type=int, default=None, help="grid points per dimension (default: the BASELINE config)")
+    ap.add_argument("--env", default=ENV, help="env plugin (default: the BASELINE metric config, "
+                    "double_pendulum_swingup at 80 bins; other BASELINE configs: cartpole_swingup@50, "
+                    "double_cartpole@25, double_cartpole_swingup@25, pendulum@200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-transition-cache", action="store_true",
-                    help="recompute the dynamics in every evaluation sweep (reference behaviour)")
+    ap.add_argument("--transition-cache", action="store_true",
+                    help="record transitions on the first evaluation sweep of a step and replay them "
+                         "on the others (default: recompute the dynamics every sweep, as the reference)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22)
     args = ap.parse_args()
 
@@ -109,9 +113,11 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    cls = envs.ENVS[ENV]
-    cfg = envs.CudaPIConfig(**cls.CONFIG, cache_transitions=not args.no_transition_cache)
-    solver = envs.make(ENV, args.bins, config=cfg, device=dev)
+    cls = envs.ENVS[args.env]
+    if args.bins is None:
+        args.bins = BINS if args.env == ENV else cls.DEFAULT_BINS
+    cfg = envs.CudaPIConfig(**cls.CONFIG, cache_transitions=args.transition_cache)
+    solver = envs.make(args.env, args.bins, config=cfg, device=dev)
     n, nA, D = solver.n_states, solver.n_actions, cls._D
     gamma = float(np.float32(solver.config.gamma))
 
@@ -189,6 +195,18 @@ def main() -> None:
         "improve_sweep": roof("pi_improve_sweep_kernel", bytes_improve, states_per_launch * nA,
                               improve_ms),
     }
+    # HBM traffic per launch from the committed PMC passes of this same command
+    # (tools/profile_bench.sh -> profiles/rNN/traffic_bench_c4.json), gfx950-corrected.
+    if world == 1:
+        for tf in sorted(ROOT.glob("profiles/r*/traffic_bench_c4.json"), reverse=True):
+            t = json.loads(tf.read_text())
+            if t.get("states") == n:
+                for k in kernels.values():
+                    hit = t["kernels"].get(k["kernel"])
+                    if hit:
+                        k["traffic"] = hit["hbm_bytes_corrected"]
+                        k["traffic_source"] = str(tf.relative_to(ROOT))
+                break
     share = {"first_eval_sweep": first_ms, "other_eval_sweeps": rest_ms * (EVAL_PER_STEP - 1),
              "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dominant = max(share, key=share.get)
@@ -206,8 +224,8 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"double-pendulum swing-up 4D grid bins={args.bins}/dim "
-                               f"({n} states) x {nA} actions, gamma=0.999; step = {EVAL_PER_STEP} "
+        "config": {"workload": f"{args.env} {D}D grid bins={args.bins}/dim "
+                               f"({n} states) x {nA} actions, gamma={solver.config.gamma}; step = {EVAL_PER_STEP} "
                                f"eval sweeps + {IMPROVE_PER_STEP} improve sweep = {backups_per_step} backups",
                    "states": n, "actions": nA, "eval_sweeps_per_step": EVAL_PER_STEP,
                    "improve_sweeps_per_step": IMPROVE_PER_STEP, "transition_cache": cached,
@@ -222,7 +240,7 @@ def main() -> None:
                   "replay_states_per_thread": eng.info(9)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -65,8 +65,10 @@ class CudaPIConfig:
     max_pi_iter: int = 50         # outer evaluate/improve iterations, at most
     log_interval: int = 100       # log the residual every N sweeps (at check points)
     # MI355X extension (results are bit-identical either way): record each state's transition
-    # on the first sweep of a policy evaluation and replay it on the following sweeps.
-    cache_transitions: bool = True
+    # on the first sweep of a policy evaluation and replay it on the following sweeps.  Off by
+    # default: on MI355X the sweeps are bound by the scattered V gather, not by the dynamics
+    # arithmetic, so replaying is only worth ~15 % on 4-D grids and loses on 6-D.
+    cache_transitions: bool = False
 
 
 class HipSweepBackend:
