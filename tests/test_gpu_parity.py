@@ -20,6 +20,14 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["flat", "tiled"])
+def kernel_family(request, monkeypatch):
+    """Every parity test runs against both evaluation-kernel families: the flat
+    one-state-per-lane sweeps and the tile-staged (LDS box) sweeps."""
+    monkeypatch.setenv("PI_MI355_TILED", "1" if request.param == "tiled" else "0")
+    return request.param
+
+
 def _torch():
     import torch
     return torch
