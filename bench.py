@@ -180,6 +180,8 @@ def main() -> None:
     bytes_eval = algorithmic_bytes_eval(D)
     bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
 
+    tiled = bool(solver._backend.engine.info(10))
+
     def roof(kernel, bytes_per_backup, backups, ms):
         ach = bytes_per_backup * backups / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -188,9 +190,11 @@ def main() -> None:
                 "avg_launch_ms": ms}
 
     kernels = {
-        "first_eval_sweep": roof("pi_eval_build_kernel" if cached else "pi_eval_sweep_kernel",
+        "first_eval_sweep": roof(("pi_tile_build_kernel" if tiled else "pi_eval_build_kernel") if cached
+                                 else ("pi_tile_eval_kernel" if tiled else "pi_eval_sweep_kernel"),
                                  bytes_eval, states_per_launch, first_ms),
-        "other_eval_sweeps": roof("pi_eval_replay_kernel" if cached else "pi_eval_sweep_kernel",
+        "other_eval_sweeps": roof(("pi_tile_replay_kernel" if tiled else "pi_eval_replay_kernel") if cached
+                                  else ("pi_tile_eval_kernel" if tiled else "pi_eval_sweep_kernel"),
                                   bytes_eval, states_per_launch, rest_ms),
         "improve_sweep": roof("pi_improve_sweep_kernel", bytes_improve, states_per_launch * nA,
                               improve_ms),
@@ -237,7 +241,9 @@ def main() -> None:
         "improve_backups_per_s": states_per_launch * world * nA / (improve_ms * 1e-3),
         "check": {"last_residual": last_delta, "last_changed": last_changed,
                   "vgpr_eval": eng.info(4), "vgpr_improve": eng.info(5), "vgpr_replay": eng.info(8),
-                  "replay_states_per_thread": eng.info(9)},
+                  "replay_states_per_thread": eng.info(9), "tiled": bool(eng.info(10)),
+                  "tile": [eng.info(30 + d) for d in range(D)], "box": [eng.info(20 + d) for d in range(D)],
+                  "reach": [eng.info(40 + d) for d in range(D)], "tiled_blocks": eng.info(11)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)

@@ -474,6 +474,50 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
     }
 }
 
+// ---- which dim-0 planes of V can the states of a range read? -----------------------------
+// For every state in [s_begin, s_end) and EVERY action: the plane (dimension-0 index) of the
+// successor's cell and the one above it are marked in a bitmap of g_0 bits.  Policy-independent,
+// so it is computed once; the multi-GPU host uses it to exchange only the planes a rank's
+// shard can reach (halo exchange) instead of all-gathering the whole V after every sweep.
+#define PI_PLANE_WORDS ((PI_GRID.g[0] + 31) / 32)
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_reach_planes_kernel(const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                       long long s_begin, long long s_end, unsigned int* __restrict__ bitmap) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ unsigned int lds_bits[PI_PLANE_WORDS];
+    for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+    for (int i = threadIdx.x; i < PI_PLANE_WORDS; i += PI_BLOCK) lds_bits[i] = 0u;
+    __syncthreads();
+    const PiChunks ck = pi_chunks(s_end - s_begin);
+    for (long long cl = ck.j; cl < ck.span; cl += ck.step) {
+        const long long chunk = ck.x * ck.span + cl;
+        if (chunk >= ck.n_chunks) break;
+        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
+        if (s >= s_end) continue;
+        if (term[s]) continue;
+        float x[PI_D];
+        pi_state_coords((unsigned int)s, lds_tab, x);
+        int last = -1;
+        for (int a = 0; a < PI_NA; ++a) {
+            float ns[PI_D], reward, fr[PI_D];
+            bool done;
+            pi_dynamics(x, tab[PI_TAB_ACT + a], ns, &reward, &done);
+            if (done) continue;
+            int base;
+            pi_locate(ns, tab, base, fr);
+            const int p = base / PI_GRID.stride[0];
+            if (p != last) {
+                atomicOr(&lds_bits[p >> 5], 1u << (p & 31));
+                atomicOr(&lds_bits[(p + 1) >> 5], 1u << ((p + 1) & 31));
+                last = p;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PI_PLANE_WORDS; i += PI_BLOCK)
+        if (lds_bits[i] != 0u) atomicOr(&bitmap[i], lds_bits[i]);
+}
+
 // ---- plugin probe (parity tests for the env dynamics and the interpolation) ------
 // One thread per query point: runs step_dynamics on (state, action) and, when `idxs`
 // is given, the interpolation of an arbitrary point.  Not on the hot path.

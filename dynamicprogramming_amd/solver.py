@@ -116,6 +116,14 @@ class HipSweepBackend:
             self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
                                     s_begin, s_end, gamma, n_sweeps, delta_ptr, self._stream())
 
+    def reach_planes(self, term, s_begin, s_end, n_planes):
+        """bool[n_planes]: dimension-0 planes of V the states of the range can read (any action)."""
+        words = (n_planes + 31) // 32
+        bitmap = self.torch.zeros(words, dtype=self.torch.int32, device=self.device)
+        self.engine.reach_planes(term.data_ptr(), s_begin, s_end, bitmap.data_ptr(), self._stream())
+        bits = bitmap.cpu().numpy().view(np.uint32)
+        return ((bits[np.arange(n_planes) >> 5] >> (np.arange(n_planes) & 31).astype(np.uint32)) & 1).astype(bool)
+
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), term.data_ptr(), s_begin, s_end,
                                   gamma, 0 if d_changed is None else d_changed.data_ptr(),
@@ -257,6 +265,7 @@ class _CudaPolicyIterationBase(abc.ABC):
             self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
             logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
         self.d_new_value_function.copy_(self.d_value_function)
+        self._plan_exchange()
         logger.success("Kernels compiled. Device memory allocated.")
 
     def _seed_values(self, mask: np.ndarray, value: float) -> None:
@@ -295,6 +304,98 @@ class _CudaPolicyIterationBase(abc.ABC):
             mine = mine.clone()                 # gloo: no aliasing between input and output
         dist.all_gather_into_tensor(full, mine, group=self._process_group)
 
+    def _plan_exchange(self) -> None:
+        """How V' travels between ranks after an evaluation sweep.  A state's successor lies a
+        few cells away, so a rank's shard only ever reads a band of dimension-0 planes around
+        itself (plus the opposite end where an angle wraps).  Every rank measures that band once
+        (all actions, `pi_reach_planes`), the bitmaps are all-gathered, and from then on each rank
+        sends exactly the plane runs its peers can reach (point-to-point over RCCL/xGMI) instead
+        of all-gathering the whole V.  Falls back to the all-gather when the bands cover most of
+        the grid anyway.  `PI_MI355_EXCHANGE=allgather|halo` forces a mode."""
+        import os
+        self._segments = None
+        if self._world == 1:
+            return
+        import torch
+        import torch.distributed as dist
+        mode = os.environ.get("PI_MI355_EXCHANGE", "auto")
+        if mode == "allgather" or not hasattr(self._backend, "reach_planes"):
+            return
+        g0 = int(self.grid_shape[0])
+        n, per = self.n_states, self._shard_len
+        stride0 = n // g0
+        mine = np.zeros(g0, dtype=bool)
+        if self._s_end > self._s_begin:
+            mine = self._backend.reach_planes(self.d_terminal_mask, self._s_begin, self._s_end, g0)
+        dev = self.d_value_function.device
+        allbits = torch.zeros(self._world * g0, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allbits, torch.from_numpy(mine.astype(np.uint8)).to(dev),
+                                    group=self._process_group)
+        allbits = allbits.cpu().numpy().astype(bool).reshape(self._world, g0)
+        segments = []
+        for dst in range(self._world):
+            need = allbits[dst]
+            p = 0
+            while p < g0:
+                if not need[p]:
+                    p += 1
+                    continue
+                q = p
+                while q < g0 and need[q]:
+                    q += 1
+                lo, hi = p * stride0, min(q * stride0, n)
+                for src in range(self._world):
+                    a, b = max(lo, src * per), min(hi, min((src + 1) * per, n))
+                    if src != dst and a < b:
+                        segments.append((src, dst, a, b))
+                p = q
+        recv = [sum(b - a for (_, d, a, b) in segments if d == r) for r in range(self._world)]
+        full = self._n_pad - per
+        if mode != "halo" and max(recv) > 0.6 * full:
+            logger.info(f"halo exchange would move {max(recv) / max(full, 1):.0%} of an all-gather: "
+                        "keeping the all-gather")
+            return
+        self._segments = segments
+        self._peer = [dist.get_global_rank(self._process_group, r) if self._process_group is not None
+                      else r for r in range(self._world)]
+        # Self-test on the real transport before trusting it: every rank writes "flat index" into
+        # its own shard of the scratch buffer, exchanges, and checks each plane it may read.
+        scratch = self.d_new_value_function
+        scratch.fill_(-1.0)
+        if self._s_end > self._s_begin:
+            scratch[self._s_begin:self._s_end] = torch.arange(
+                self._s_begin, self._s_end, dtype=torch.float32, device=dev)
+        self._exchange_shards(scratch)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        for p in np.flatnonzero(mine):
+            a, b = int(p) * stride0, min((int(p) + 1) * stride0, n)
+            want = torch.arange(a, b, dtype=torch.float32, device=dev)
+            bad += (scratch[a:b] != want).any().to(torch.int32)
+        self._all_reduce_scalar(bad, "SUM")
+        scratch.copy_(self.d_value_function)
+        if int(bad.item()) != 0:
+            logger.warning("halo exchange self-test failed; falling back to the all-gather")
+            self._segments = None
+            return
+        logger.info(f"halo exchange: rank {self._rank} receives {recv[self._rank] * 4 / 2**20:.1f} MiB "
+                    f"per sweep instead of {full * 4 / 2**20:.1f} MiB")
+
+    def _exchange_shards(self, full) -> None:
+        """Make the freshly swept shard of `full` visible where other ranks will read it."""
+        if self._segments is None:
+            self._all_gather_shards(full)
+            return
+        import torch.distributed as dist
+        ops = []
+        for src, dst, a, b in self._segments:
+            if src == self._rank:
+                ops.append(dist.P2POp(dist.isend, full[a:b], self._peer[dst], self._process_group))
+            elif dst == self._rank:
+                ops.append(dist.P2POp(dist.irecv, full[a:b], self._peer[src], self._process_group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
     def _all_reduce_scalar(self, t, op) -> None:
         import torch.distributed as dist
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op), group=self._process_group)
@@ -317,7 +418,7 @@ class _CudaPolicyIterationBase(abc.ABC):
                                       self.d_policy, self.d_terminal_mask, self._s_begin,
                                       self._s_end, gamma, 1, self._d_delta if k == n - 1 else None,
                                       rebuild=rebuild and k == 0)
-            self._all_gather_shards(self.d_new_value_function)
+            self._exchange_shards(self.d_new_value_function)
             self.d_value_function, self.d_new_value_function = (
                 self.d_new_value_function, self.d_value_function)
         self._all_reduce_scalar(self._d_delta, "MAX")
@@ -394,6 +495,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         logger.info("Pulling results from device memory...")
         if self._world > 1:
             self._all_gather_shards(self.d_policy)
+            self._all_gather_shards(self.d_value_function)     # halo mode: V is only local + halos
         n = self.n_states
         self.value_function = self.d_value_function[:n].cpu().numpy()
         self.policy = self.d_policy[:n].cpu().numpy()

@@ -128,6 +128,16 @@ int pi_improve_sweep(pi_handle* h, const float* V, int32_t* policy, const uint8_
                      void* stream);
 
 /*
+ * Which dimension-0 planes of V can the states of [s_begin, s_end) read, under ANY action?
+ * d_bitmap (device, ceil(grid_shape[0] / 32) uint32 words, zeroed here) receives one bit per
+ * plane: the plane of every successor cell and the plane above it.  No counterpart in the
+ * reference (it has no multi-GPU path); the multi-GPU host uses it to exchange only reachable
+ * planes between ranks instead of all-gathering V after every sweep.
+ */
+int pi_reach_planes(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end,
+                    uint32_t* d_bitmap, void* stream);
+
+/*
  * Probes used by the parity tests (not on the hot path): run the compiled plugin /
  * interpolation on m arbitrary points.  All pointers are device pointers.
  *   pi_probe_step   : states (m,D), acts (m) -> next (m,D), reward (m), done (m)

@@ -118,6 +118,19 @@ class OracleSweepBackend:
             if d_delta is not None and i == n_sweeps - 1:
                 d_delta[0] = delta
 
+    def reach_planes(self, term, s_begin, s_end, n_planes):
+        """CPU restatement of pi_reach_planes: planes of every successor cell (+1), any action."""
+        n = self.n
+        out = np.zeros(n_planes, dtype=bool)
+        live = ~term.numpy()[:n][s_begin:s_end].astype(bool)
+        st = self.states[s_begin:s_end][live]
+        for a in self.actions:
+            nxt, _, done = self.lib.step(st, a)
+            idx, _ = self.lib.interp(nxt[~done], self.lo, self.hi, self.shape, self.strides)
+            planes = np.unique(idx // int(self.strides[0]))
+            out[planes] = True
+        return out
+
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         n = self.n
         new_pol, changed = self.lib.improve_sweep(self.states, self.actions, policy.numpy()[:n],

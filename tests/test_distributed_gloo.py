@@ -24,8 +24,11 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, out_dir: str) -> None:
+def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, out_dir: str,
+            exchange: str = "auto") -> None:
     sys.path.insert(0, str(ROOT))
+    import os
+    os.environ["PI_MI355_EXCHANGE"] = exchange
     import torch
     import torch.distributed as dist
     from dynamicprogramming_amd import envs
@@ -43,22 +46,26 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         assert (s._s_begin, s._s_end) == (min(rank * per, n), min((rank + 1) * per, n))
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
-                 sweeps=np.asarray(s.stats["sweeps_per_iter"]), evals=s._backend.calls["eval"])
+                 sweeps=np.asarray(s.stats["sweeps_per_iter"]), evals=s._backend.calls["eval"],
+                 halo=np.int64(-1 if s._segments is None else
+                               sum(b - a for (_, d, a, b) in s._segments if d == rank)))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
 @pytest.mark.parametrize("world,name,shape", [(2, "mountain_car", (23, 19)),      # 437 states: odd
-                                               (3, "cartpole", (5, 4, 7, 3)),       # 420 = 3*140
-                                               (2, "double_cartpole", (3, 2, 3, 3, 3, 3))])   # 486
-def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, tmp_path):
+                                               (3, "cartpole", (9, 4, 7, 3)),       # 756 = 3*252
+                                               (2, "double_cartpole", (3, 2, 3, 3, 3, 3)),   # 486
+                                               (4, "pendulum", (41, 13))])          # angle wraps
+def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, exchange, tmp_path):
     import torch.multiprocessing as mp
     from dynamicprogramming_amd import envs
     from dynamicprogramming_amd.solver import CudaPIConfig
     from tests import helpers as H
-    cfg_kw = {**envs.ENVS[name].CONFIG, "max_pi_iter": 4, "max_eval_iter": 120}
-    mp.spawn(_worker, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path)), nprocs=world,
-             join=True)
+    cfg_kw = {**envs.ENVS[name].CONFIG, "max_pi_iter": 3, "max_eval_iter": 60}
+    mp.spawn(_worker, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path), exchange),
+             nprocs=world, join=True)
     cls = envs.ENVS[name]
     single = cls(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw),
                  backend_factory=H.OracleSweepBackend)
@@ -69,3 +76,4 @@ def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, tmp_pat
         assert np.array_equal(got["policy"], single.policy)
         assert got["sweeps"].tolist() == single.stats["sweeps_per_iter"]
         assert int(got["evals"]) == single.stats["eval_sweeps"]      # one launch per sweep per rank
+        assert (int(got["halo"]) >= 0) == (exchange == "halo")

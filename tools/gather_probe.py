@@ -18,7 +18,8 @@ import torch
 from dynamicprogramming_amd import _native, envs
 
 bins_n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
-only = sys.argv[2:]
+only = [a for a in sys.argv[2:] if not a.startswith("policy=")]
+pol_mode = ([a.split("=")[1] for a in sys.argv[2:] if a.startswith("policy=")] or ["random"])[0]
 SIG = "float a, float b, float c, float d, float u, float* na, float* nb, float* nc, float* nd, float* r, bool* t"
 DYN = {
     "identity": f"__device__ void step_dynamics({SIG}) {{ *na=a; *nb=b; *nc=c; *nd=d; *r=1.0f; *t=false; }}",
@@ -35,6 +36,11 @@ gen = torch.Generator(device="cpu").manual_seed(0)
 V = torch.randn(n, generator=gen).to(dev)
 Vb = torch.empty_like(V)
 pol = torch.randint(0, 11, (n,), generator=gen, dtype=torch.int32).to(dev)
+if pol_mode == "const":
+    pol.fill_(5)
+elif pol_mode == "blocks":      # piecewise-constant policy: action changes every 8 cells of dim 1
+    idx = torch.arange(n, device=dev)
+    pol = ((idx // (bins_n ** 2 * 8)) % 11).to(torch.int32)
 term = torch.zeros(n, dtype=torch.uint8, device=dev)
 for name, dyn in DYN.items():
     if only and name not in only:
@@ -59,5 +65,6 @@ for name, dyn in DYN.items():
     e1.record()
     torch.cuda.synchronize()
     ms2 = e0.elapsed_time(e1) / 10
+    print(f"[{pol_mode}] tiled={eng.info(10)} box={[eng.info(20 + d) for d in range(4)]} ", end="")
     print(f"{name:10s} replay {ms:.3f} ms/sweep   recompute {ms2:.3f} ms/sweep   ({n / ms / 1e6:.1f} G states/s replay)")
     eng.close()
