@@ -314,6 +314,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         the grid anyway.  `PI_MI355_EXCHANGE=allgather|halo` forces a mode."""
         import os
         self._segments = None
+        self._send_ranges = self._interior_ranges = None
         if self._world == 1:
             return
         import torch
@@ -377,14 +378,33 @@ class _CudaPolicyIterationBase(abc.ABC):
             logger.warning("halo exchange self-test failed; falling back to the all-gather")
             self._segments = None
             return
+        # Sub-ranges of this rank's shard: what peers wait for (swept first, then sent while the
+        # rest is swept).  Disabled with the transition cache (its records are per range).
+        self._send_ranges = self._interior_ranges = None
+        if getattr(self._backend, "_cache", None) is None and os.environ.get("PI_MI355_OVERLAP", "1") != "0":
+            cuts = sorted({(a, b) for (src, _, a, b) in segments if src == self._rank})
+            merged = []
+            for a, b in cuts:
+                if merged and a <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], b)
+                else:
+                    merged.append([a, b])
+            interior, pos = [], self._s_begin
+            for a, b in merged:
+                if a > pos:
+                    interior.append((pos, a))
+                pos = max(pos, b)
+            if pos < self._s_end:
+                interior.append((pos, self._s_end))
+            self._send_ranges = [tuple(m) for m in merged]
+            self._interior_ranges = interior
+            self._d_delta_parts = torch.zeros(len(merged) + len(interior) + 1, dtype=torch.float32,
+                                              device=dev)
         logger.info(f"halo exchange: rank {self._rank} receives {recv[self._rank] * 4 / 2**20:.1f} MiB "
                     f"per sweep instead of {full * 4 / 2**20:.1f} MiB")
 
-    def _exchange_shards(self, full) -> None:
-        """Make the freshly swept shard of `full` visible where other ranks will read it."""
-        if self._segments is None:
-            self._all_gather_shards(full)
-            return
+    def _start_exchange(self, full) -> list:
+        """Post the halo sends/receives for `full`; returns the requests to wait on."""
         import torch.distributed as dist
         ops = []
         for src, dst, a, b in self._segments:
@@ -392,9 +412,15 @@ class _CudaPolicyIterationBase(abc.ABC):
                 ops.append(dist.P2POp(dist.isend, full[a:b], self._peer[dst], self._process_group))
             elif dst == self._rank:
                 ops.append(dist.P2POp(dist.irecv, full[a:b], self._peer[src], self._process_group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _exchange_shards(self, full) -> None:
+        """Make the freshly swept shard of `full` visible where other ranks will read it."""
+        if self._segments is None:
+            self._all_gather_shards(full)
+            return
+        for req in self._start_exchange(full):
+            req.wait()
 
     def _all_reduce_scalar(self, t, op) -> None:
         import torch.distributed as dist
@@ -413,12 +439,35 @@ class _CudaPolicyIterationBase(abc.ABC):
                 self.d_value_function, self.d_new_value_function = (
                     self.d_new_value_function, self.d_value_function)
             return
+        overlap = self._segments is not None and self._send_ranges is not None
         for k in range(n):
-            self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                      self.d_policy, self.d_terminal_mask, self._s_begin,
-                                      self._s_end, gamma, 1, self._d_delta if k == n - 1 else None,
-                                      rebuild=rebuild and k == 0)
-            self._exchange_shards(self.d_new_value_function)
+            last = k == n - 1
+            if overlap:
+                # Sweep the planes other ranks are waiting for, hand them to RCCL, and sweep the
+                # interior while they travel (RCCL runs on its own stream).
+                parts = self._d_delta_parts
+                i = 0
+                for a, b in self._send_ranges:
+                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                              self.d_policy, self.d_terminal_mask, a, b, gamma, 1,
+                                              parts[i:i + 1] if last else None, rebuild=True)
+                    i += 1
+                reqs = self._start_exchange(self.d_new_value_function)
+                for a, b in self._interior_ranges:
+                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                              self.d_policy, self.d_terminal_mask, a, b, gamma, 1,
+                                              parts[i:i + 1] if last else None, rebuild=True)
+                    i += 1
+                for req in reqs:
+                    req.wait()
+                if last:
+                    self._d_delta.copy_(parts[:i].max().reshape(1))
+            else:
+                self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
+                                          self.d_policy, self.d_terminal_mask, self._s_begin,
+                                          self._s_end, gamma, 1, self._d_delta if last else None,
+                                          rebuild=rebuild and k == 0)
+                self._exchange_shards(self.d_new_value_function)
             self.d_value_function, self.d_new_value_function = (
                 self.d_new_value_function, self.d_value_function)
         self._all_reduce_scalar(self._d_delta, "MAX")

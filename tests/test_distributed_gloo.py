@@ -75,5 +75,8 @@ def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, exchang
         H.assert_bits_equal(got["V"], single.value_function, f"rank {r} V")
         assert np.array_equal(got["policy"], single.policy)
         assert got["sweeps"].tolist() == single.stats["sweeps_per_iter"]
-        assert int(got["evals"]) == single.stats["eval_sweeps"]      # one launch per sweep per rank
+        if exchange == "allgather":
+            assert int(got["evals"]) == single.stats["eval_sweeps"]  # one launch per sweep per rank
+        else:                                                        # boundary + interior launches
+            assert int(got["evals"]) >= single.stats["eval_sweeps"]
         assert (int(got["halo"]) >= 0) == (exchange == "halo")
