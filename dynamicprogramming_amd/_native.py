@@ -42,6 +42,8 @@ SIGNATURES = {
                                              ctypes.c_size_t, _vp, _vp]),
     "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, _vp, _vp]),
+    "pi_value_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_float, _vp, _vp, _vp]),
     "pi_reach_planes": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp]),
     "pi_probe_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
     "pi_probe_interp": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
@@ -172,6 +174,10 @@ class Engine:
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
         _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,
                                       d_changed or None, stream or None), "pi_improve_sweep")
+
+    def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta=0, d_changed=0, stream=0):
+        _check(lib().pi_value_sweep(self._h, V, Vnew, policy, term, s_begin, s_end, gamma,
+                                    d_delta or None, d_changed or None, stream or None), "pi_value_sweep")
 
     def reach_planes(self, term, s_begin, s_end, d_bitmap, stream=0):
         _check(lib().pi_reach_planes(self._h, term, s_begin, s_end, d_bitmap, stream or None),

@@ -223,6 +223,14 @@ __device__ __forceinline__ float pi_wave_max(float v) {
 //   base >= 0 : flat index of the cell's lowest corner
 //   base = -1 : the transition terminates (E = 0, V' = reward + gamma * 0)
 //   base = -2 : terminal grid node (V' = V)
+#ifndef PI_STREAM_NT
+#define PI_STREAM_NT 1
+#endif
+#if PI_STREAM_NT
+#define PI_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define PI_STREAM_LOAD(p) (*(p))
+#endif
 #define PI_REC_DONE (-1)
 #define PI_REC_TERMINAL (-2)
 #ifndef PI_SPT
@@ -274,10 +282,12 @@ __device__ __forceinline__ void pi_eval_body(const float* __restrict__ V, float*
         float reward = 0.0f, fr[PI_D];
 #pragma unroll
         for (int d = 0; d < PI_D; ++d) fr[d] = 0.0f;
-        if (!term[s]) {
+        // policy and mask are read exactly once per sweep: stream them (nt) so they do not
+        // displace V lines, which every neighbouring state re-reads, from L2 / Infinity Cache.
+        if (!PI_STREAM_LOAD(&term[s])) {
             float x[PI_D], ns[PI_D];
             pi_state_coords((unsigned int)s, lds_tab, x);
-            const float a = lds_tab[PI_TAB_ACT + policy[s]];
+            const float a = lds_tab[PI_TAB_ACT + PI_STREAM_LOAD(&policy[s])];
             bool done;
             pi_dynamics(x, a, ns, &reward, &done);
             float e = 0.0f;
@@ -438,23 +448,33 @@ pi_eval_replay_kernel(const float* __restrict__ V, float* __restrict__ Vn,
 // ---- greedy policy improvement sweep -------------------------------------------
 // policy[s] = argmax_a [ r(s,a) + gamma * E[V](s'_a) ], first maximum wins; terminal
 // states keep their entry.  changed (nullable): number of entries that changed.
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
-pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
-                        const unsigned char* __restrict__ term, const float* __restrict__ tab,
-                        long long s_begin, long long s_end, float gamma,
-                        unsigned int* __restrict__ changed) {
+// WRITE_V (value-iteration sweep, the fused form the reference's README sketches at :790-799
+// but does not implement): also Vn[s] = max_a Q(s,a) (terminal: copy) and the residual.
+template <bool WRITE_V>
+__device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, float* __restrict__ Vn,
+                                                int* __restrict__ policy,
+                                                const unsigned char* __restrict__ term,
+                                                const float* __restrict__ tab, long long s_begin,
+                                                long long s_end, float gamma,
+                                                unsigned int* __restrict__ delta_bits,
+                                                unsigned int* __restrict__ changed) {
     __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ float lds_red[PI_BLOCK / 64];
     for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
     __syncthreads();
 
     const PiChunks ck = pi_chunks(s_end - s_begin);
     unsigned int n_changed = 0;
+    float dmax = 0.0f;
     for (long long cl = ck.j; cl < ck.span; cl += ck.step) {
         const long long chunk = ck.x * ck.span + cl;
         if (chunk >= ck.n_chunks) break;
         const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
         if (s >= s_end) continue;
-        if (term[s]) continue;
+        if (term[s]) {
+            if (WRITE_V) Vn[s] = V[s];
+            continue;
+        }
         float x[PI_D];
         pi_state_coords((unsigned int)s, lds_tab, x);
         float best_q = -1.0e30f;
@@ -466,12 +486,34 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
         const int old = policy[s];
         policy[s] = best;
         n_changed += (old != best) ? 1u : 0u;
+        if (WRITE_V) {
+            Vn[s] = best_q;
+            const float dlt = fabsf(best_q - V[s]);
+            dmax = dlt > dmax ? dlt : dmax;
+        }
     }
     if (changed != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) n_changed += __shfl_xor(n_changed, o, 64);
         if ((threadIdx.x & 63) == 0 && n_changed != 0u) atomicAdd(changed, n_changed);
     }
+    if (WRITE_V && delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
+}
+
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
+                        const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                        long long s_begin, long long s_end, float gamma,
+                        unsigned int* __restrict__ changed) {
+    pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed);
+}
+
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_value_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn, int* __restrict__ policy,
+                      const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                      long long s_begin, long long s_end, float gamma,
+                      unsigned int* __restrict__ delta_bits, unsigned int* __restrict__ changed) {
+    pi_improve_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, changed);
 }
 
 // ---- which dim-0 planes of V can the states of a range read? -----------------------------

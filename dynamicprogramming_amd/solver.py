@@ -129,6 +129,11 @@ class HipSweepBackend:
                                   gamma, 0 if d_changed is None else d_changed.data_ptr(),
                                   self._stream())
 
+    def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta, d_changed):
+        self.engine.value_sweep(V.data_ptr(), Vnew.data_ptr(), policy.data_ptr(), term.data_ptr(),
+                                s_begin, s_end, gamma, 0 if d_delta is None else d_delta.data_ptr(),
+                                0 if d_changed is None else d_changed.data_ptr(), self._stream())
+
     def close(self):
         self._cache = None
         self.engine.close()
@@ -538,6 +543,69 @@ class _CudaPolicyIterationBase(abc.ABC):
             logger.warning(f"Policy Iteration hit max_pi_iter={self.config.max_pi_iter}.")
             self.stats["stable"] = False
         self._pull_tensors_from_gpu()
+
+    # ── extensions beyond the reference API ─────────────
+    def value_iteration(self, max_iter: int | None = None) -> float:
+        """Fused value-iteration sweeps: V' = max_a Q and policy = argmax in one kernel, until the
+        residual (looked at every 25 sweeps like the evaluation loop) drops below theta or
+        `max_iter` (default config.max_eval_iter) sweeps are done.  Returns the last residual.
+        The reference's README sketches this fused form (:790-799); its code does not have it."""
+        cfg = self.config
+        gamma = float(np.float32(cfg.gamma))
+        limit = cfg.max_eval_iter if max_iter is None else int(max_iter)
+        delta = float("inf")
+        sweeps = 0
+        for i in range(limit):
+            check = i % SYNC_INTERVAL == 0 or i == limit - 1
+            self._backend.value_sweep(self.d_value_function, self.d_new_value_function, self.d_policy,
+                                      self.d_terminal_mask, self._s_begin, self._s_end, gamma,
+                                      self._d_delta if check else None, None)
+            if self._world > 1:
+                self._exchange_shards(self.d_new_value_function)
+            self.d_value_function, self.d_new_value_function = (
+                self.d_new_value_function, self.d_value_function)
+            sweeps += 1
+            if check:
+                if self._world > 1:
+                    self._all_reduce_scalar(self._d_delta, "MAX")
+                delta = float(self._d_delta.item())
+                if delta < cfg.theta:
+                    break
+        self._records_stale = True
+        self.stats["value_sweeps"] = self.stats.get("value_sweeps", 0) + sweeps
+        return delta
+
+    def save_checkpoint(self, filepath) -> None:
+        """Mid-run snapshot (V, policy, counters) that `load_checkpoint` can resume from; the
+        reference can only save after run() has dropped its device arrays (:392-409)."""
+        filepath = Path(filepath).with_suffix(".npz")
+        filepath.parent.mkdir(parents=True, exist_ok=True)
+        n = self.n_states
+        if self._world > 1:
+            self._all_gather_shards(self.d_policy)
+            self._all_gather_shards(self.d_value_function)
+        np.savez(filepath, value_function=self.d_value_function[:n].cpu().numpy(),
+                 policy=self.d_policy[:n].cpu().numpy(), grid_shape=self.grid_shape,
+                 action_space=self.action_space,
+                 eval_sweeps=np.int64(self.stats["eval_sweeps"]),
+                 improve_sweeps=np.int64(self.stats["improve_sweeps"]),
+                 pi_iterations=np.int64(self.stats["pi_iterations"]))
+
+    def load_checkpoint(self, filepath) -> None:
+        """Restore V and the policy of a `save_checkpoint` file into this (freshly constructed)
+        solver; `run()` then continues from there."""
+        import torch
+        data = np.load(Path(filepath).with_suffix(".npz"))
+        if not (np.array_equal(data["grid_shape"], self.grid_shape)
+                and np.array_equal(data["action_space"], self.action_space)):
+            raise ValueError("checkpoint was written for a different grid or action set")
+        n, dev = self.n_states, self.d_value_function.device
+        self.d_value_function[:n].copy_(torch.from_numpy(data["value_function"]).to(dev))
+        self.d_new_value_function.copy_(self.d_value_function)
+        self.d_policy[:n].copy_(torch.from_numpy(data["policy"]).to(dev))
+        for key in ("eval_sweeps", "improve_sweeps", "pi_iterations"):
+            self.stats[key] = int(data[key])
+        self._records_stale = True
 
     def _pull_tensors_from_gpu(self) -> None:
         """Copy V and the policy to host arrays and drop every device array (:372-388)."""

@@ -128,6 +128,18 @@ int pi_improve_sweep(pi_handle* h, const float* V, int32_t* policy, const uint8_
                      void* stream);
 
 /*
+ * Value-iteration sweep over [s_begin, s_end): Vnew[s] = max_a Q(s, a) and policy[s] = argmax
+ * in one pass (terminal states copy V and keep their policy entry).  This is the fused form the
+ * reference's README sketches (README.md:790-799, "V_new <- best_Q") but does not implement —
+ * its code alternates policy_eval_kernel / policy_improve_kernel.  d_delta (nullable, zeroed
+ * here) receives max|Vnew - V|, d_changed (nullable, zeroed here) the number of policy entries
+ * that changed.
+ */
+int pi_value_sweep(pi_handle* h, const float* V, float* Vnew, int32_t* policy, const uint8_t* term,
+                   int64_t s_begin, int64_t s_end, float gamma, float* d_delta, uint32_t* d_changed,
+                   void* stream);
+
+/*
  * Which dimension-0 planes of V can the states of [s_begin, s_end) read, under ANY action?
  * d_bitmap (device, ceil(grid_shape[0] / 32) uint32 words, zeroed here) receives one bit per
  * plane: the plane of every successor cell and the plane above it.  No counterpart in the

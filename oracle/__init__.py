@@ -107,6 +107,11 @@ class OracleLib:
                                              _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_float, _f32p, _f32p]
         lib.oracle_improve_sweep.restype = ctypes.c_int64
+        if hasattr(lib, "oracle_value_sweep"):
+            lib.oracle_value_sweep.argtypes = [_f32p, _f32p, ctypes.c_int32, _i32p, _f32p, _f32p, _u8p,
+                                               _f32p, _f32p, _i32p, _i32p, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_float, _i64p]
+            lib.oracle_value_sweep.restype = ctypes.c_float
         lib.oracle_run.argtypes = [_f32p, _f32p, ctypes.c_int32, _i32p, _f32p, _f32p, _u8p, _f32p,
                                    _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_int32, ctypes.c_int32, _f32p, _i64p, _i32p]
@@ -176,6 +181,25 @@ class OracleLib:
         if want_q:
             return policy, int(changed), qb, qs
         return policy, int(changed)
+
+    # -- value-iteration sweep ------------------------------------------------------
+    def value_sweep(self, states, actions, policy, V, is_term, lo, hi, shape, strides, gamma,
+                    s0=0, s1=None, out=None):
+        states = _f32(states)
+        n = len(states)
+        s1 = n if s1 is None else s1
+        actions, V = _f32(actions), _f32(V)
+        policy = np.array(policy, dtype=np.int32, copy=True)
+        term = np.ascontiguousarray(is_term, dtype=np.uint8)
+        newV = np.array(V, copy=True) if out is None else out
+        lo, hi, shape, strides = _f32(lo), _f32(hi), _i32(shape), _i32(strides)
+        changed = np.zeros(1, dtype=np.int64)
+        delta = self._lib.oracle_value_sweep(_p(states, _f32p), _p(actions, _f32p), len(actions),
+                                             _p(policy, _i32p), _p(V, _f32p), _p(newV, _f32p),
+                                             _p(term, _u8p), _p(lo, _f32p), _p(hi, _f32p),
+                                             _p(shape, _i32p), _p(strides, _i32p), s0, s1,
+                                             np.float32(gamma), _p(changed, _i64p))
+        return newV, policy, float(delta), int(changed[0])
 
     # -- run() ------------------------------------------------------------------
     def run(self, states, actions, is_term, lo, hi, shape, strides, gamma, theta, max_eval_iter,

@@ -210,6 +210,34 @@ int64_t oracle_improve_sweep(const float* states, const float* actions, int32_t 
     return changed;
 }
 
+/* Value-iteration sweep (the fused form of the reference's README :790-799): newV = max_a Q,
+ * policy = argmax (strict '>' from -1e30), terminal states copy V.  Returns max|newV - V|;
+ * *changed_out receives the number of policy entries that changed. */
+float oracle_value_sweep(const float* states, const float* actions, int32_t n_actions,
+                         int32_t* policy, const float* V, float* newV, const uint8_t* is_term,
+                         const float* lo, const float* hi, const int32_t* g, const int32_t* st,
+                         int64_t s0, int64_t s1, float gamma, int64_t* changed_out) {
+    float delta = 0.0f;
+    int64_t changed = 0;
+#pragma omp parallel for schedule(static) reduction(max : delta) reduction(+ : changed)
+    for (int64_t s = s0; s < s1; ++s) {
+        if (is_term[s]) { newV[s] = V[s]; continue; }
+        float max_q = -1.0e30f;
+        int best = 0;
+        for (int a = 0; a < n_actions; ++a) {
+            float q = backup(states + s * PI_D, actions[a], V, lo, hi, g, st, gamma);
+            if (q > max_q) { max_q = q; best = a; }
+        }
+        if (policy[s] != best) ++changed;
+        policy[s] = best;
+        newV[s] = max_q;
+        float d = fabsf(max_q - V[s]);
+        if (d > delta) delta = d;
+    }
+    if (changed_out) *changed_out = changed;
+    return delta;
+}
+
 /*
  * The whole run() loop.  V and Vtmp are the two Jacobi buffers (both seeded by the
  * caller exactly as _allocate_tensors_and_compile :152-161 does); on return `V_out`

@@ -141,5 +141,16 @@ class OracleSweepBackend:
         if d_changed is not None:
             d_changed[0] = changed
 
+    def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta, d_changed):
+        n = self.n
+        _, new_pol, delta, changed = self.lib.value_sweep(
+            self.states, self.actions, policy.numpy()[:n], V.numpy()[:n], term.numpy()[:n], self.lo,
+            self.hi, self.shape, self.strides, gamma, s_begin, s_end, out=Vnew.numpy()[:n])
+        policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+        if d_delta is not None:
+            d_delta[0] = delta
+        if d_changed is not None:
+            d_changed[0] = changed
+
     def close(self):
         pass

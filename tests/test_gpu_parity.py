@@ -449,3 +449,29 @@ def test_reach_planes_matches_cpu_restatement(name, shape, cuda_device):
         want = cpu.reach_planes(c_term, a, b, int(gshape[0]))
         assert np.array_equal(got, want), (name, a, b)   # planes of all 2^D corners
     gpu.close()
+
+
+@pytest.mark.parametrize("name,shape", [("pendulum", (33, 29)), ("cartpole", (9, 7, 11, 5)),
+                                         ("double_cartpole_swingup", (5, 4, 6, 4, 5, 4))])
+def test_value_sweep_bit_exact(name, shape, cuda_device):
+    """pi_value_sweep (fused max-backup) == oracle: V', policy, residual, changed count."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, 5)
+    n = len(V)
+    gamma = float(np.float32(envs.ENVS[name].CONFIG["gamma"]))
+    d_V, d_pol = _dev(V, cuda_device), _dev(pol, cuda_device)
+    d_term = _dev(term.astype(np.uint8), cuda_device)
+    d_Vn = torch.full((n,), -9.0, dtype=torch.float32, device=cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    a, b = 3, n - 5
+    eng.value_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
+                    d_delta.data_ptr(), d_changed.data_ptr())
+    torch.cuda.synchronize()
+    o_Vn = np.full(n, -9.0, dtype=np.float32)
+    _, o_pol, o_delta, o_changed = H.oracle_for(name).value_sweep(
+        states, acts, pol, V, term, lo, hi, gshape, strides, gamma, a, b, out=o_Vn)
+    H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "value sweep V'")
+    assert np.array_equal(d_pol.cpu().numpy(), o_pol)
+    assert np.float32(d_delta.item()) == np.float32(o_delta) and int(d_changed.item()) == o_changed
+    eng.close()

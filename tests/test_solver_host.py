@@ -128,3 +128,32 @@ def test_reference_import_path():
     cfg = m.CudaPIConfig()
     assert {k: getattr(cfg, k) for k in ref_fields} == ref_fields          # reference :36-43
     assert list(cfg.__dict__)[:5] == list(ref_fields)                      # same positional order
+
+
+def test_value_iteration_and_checkpoint(tmp_path):
+    """Fused value-iteration sweeps reach the same fixed point as policy iteration (same greedy
+    policy away from ties, V within the residual bound), and a mid-run checkpoint resumes."""
+    name, shape = "mountain_car", (30, 20)
+    cfg = CudaPIConfig(gamma=0.95, theta=1e-5, max_eval_iter=2000, max_pi_iter=30)
+    pi = _solver(name, shape, cfg)
+    pi.run()
+    vi = _solver(name, shape, cfg)
+    delta = vi.value_iteration()
+    assert delta < cfg.theta and vi.stats["value_sweeps"] % 25 == 1
+    v = vi.d_value_function[: vi.n_states].numpy()
+    assert np.max(np.abs(v - pi.value_function)) < 1e-3
+    assert np.mean(vi.d_policy[: vi.n_states].numpy() == pi.policy) > 0.98
+    # checkpoint / resume: 1 PI iteration, snapshot, finish in a new solver
+    a = _solver(name, shape, cfg)
+    a.policy_evaluation()
+    a.policy_improvement()
+    a.save_checkpoint(tmp_path / "ck")
+    b = _solver(name, shape, cfg)
+    b.load_checkpoint(tmp_path / "ck")
+    assert b.stats["eval_sweeps"] == a.stats["eval_sweeps"]
+    a.run()
+    b.run()
+    assert np.array_equal(a.policy, b.policy)
+    H.assert_bits_equal(a.value_function, b.value_function, "resumed run")
+    with pytest.raises(ValueError, match="different grid"):
+        _solver(name, (20, 20), cfg).load_checkpoint(tmp_path / "ck")
