@@ -130,6 +130,7 @@ def main() -> None:
     solver.d_policy[:n].copy_(P0)
     del V0, P0
 
+    solver.autotune()            # launch geometry for THIS V / policy (outside the timed region)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     cached = getattr(solver._backend, "_cache", None) is not None
 
@@ -243,7 +244,8 @@ def main() -> None:
                   "vgpr_eval": eng.info(4), "vgpr_improve": eng.info(5), "vgpr_replay": eng.info(8),
                   "replay_states_per_thread": eng.info(9), "tiled": bool(eng.info(10)),
                   "tile": [eng.info(30 + d) for d in range(D)], "box": [eng.info(20 + d) for d in range(D)],
-                  "reach": [eng.info(40 + d) for d in range(D)], "tiled_blocks": eng.info(11)},
+                  "reach": [eng.info(40 + d) for d in range(D)], "tiled_blocks": eng.info(11),
+                  "eval_blocks_per_cu": eng.info(12), "improve_blocks_per_cu": eng.info(13)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)

@@ -34,6 +34,8 @@ SIGNATURES = {
     "pi_kernel_source": (ctypes.c_size_t, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]),
     "pi_eval_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_float, _vp, _vp]),
+    "pi_autotune_eval": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_float, _vp]),
     "pi_eval_sweeps": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, ctypes.c_int, _vp, _vp]),
     "pi_transition_cache_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int64, ctypes.c_int64]),
@@ -157,6 +159,11 @@ class Engine:
     def eval_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta=0, stream=0):
         _check(lib().pi_eval_sweep(self._h, V, Vnew, policy, term, s_begin, s_end, gamma,
                                    d_delta or None, stream or None), "pi_eval_sweep")
+
+    def autotune_eval(self, V, Vscratch, policy, term, s_begin, s_end, gamma, stream=0):
+        _check(lib().pi_autotune_eval(self._h, V, Vscratch, policy, term, s_begin, s_end, gamma,
+                                      stream or None), "pi_autotune_eval")
+        return self.info(12)
 
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta=0, stream=0):
         _check(lib().pi_eval_sweeps(self._h, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps,

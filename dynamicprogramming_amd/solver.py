@@ -116,6 +116,12 @@ class HipSweepBackend:
             self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
                                     s_begin, s_end, gamma, n_sweeps, delta_ptr, self._stream())
 
+    def autotune(self, V, Vscratch, policy, term, s_begin, s_end, gamma) -> int:
+        """Time the evaluation sweep at several workgroups-per-CU settings on this V / policy
+        and keep the fastest (blocks; Vscratch is overwritten)."""
+        return self.engine.autotune_eval(V.data_ptr(), Vscratch.data_ptr(), policy.data_ptr(),
+                                         term.data_ptr(), s_begin, s_end, gamma, self._stream())
+
     def reach_planes(self, term, s_begin, s_end, n_planes):
         """bool[n_planes]: dimension-0 planes of V the states of the range can read (any action)."""
         words = (n_planes + 31) // 32
@@ -486,11 +492,23 @@ class _CudaPolicyIterationBase(abc.ABC):
         if self._world > 1:
             self._all_reduce_scalar(self._d_changed, "SUM")
 
+    def autotune(self) -> None:
+        """Let the backend pick its launch geometry for the evaluation sweeps on the CURRENT
+        V and policy (d_new_value_function is used as scratch and restored)."""
+        if hasattr(self._backend, "autotune") and self._s_end > self._s_begin:
+            gamma = float(np.float32(self.config.gamma))
+            self._backend.autotune(self.d_value_function, self.d_new_value_function, self.d_policy,
+                                   self.d_terminal_mask, self._s_begin, self._s_end, gamma)
+            self.d_new_value_function.copy_(self.d_value_function)
+        self._tuned = True
+
     def policy_evaluation(self) -> float:
         """Jacobi sweeps under the current policy until the residual, looked at on sweeps
         0, 25, 50, ... and the last one, drops below theta (:300-336)."""
         cfg = self.config
         gamma = float(np.float32(cfg.gamma))
+        if self.stats["pi_iterations"] == 1 and not getattr(self, "_tuned", False):
+            self.autotune()      # second evaluation: V and the policy now look like the real run
         delta = float("inf")
         t0 = time.perf_counter()
         i = 0

@@ -87,6 +87,16 @@ int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* poli
                   float* d_delta, void* stream);
 
 /*
+ * Pick the number of workgroups per CU for the evaluation sweeps by timing them on the caller's
+ * own V / policy (candidates 2..8; the gather-bound sweeps prefer few states in flight per XCD,
+ * the arithmetic-bound ones prefer occupancy — it depends on the env and on the policy).
+ * Vscratch is overwritten.  BLOCKS on the stream (event synchronise): call it outside any timed
+ * or captured region.  No-op when PI_MI355_EVAL_BLOCKS_PER_CU pins the value or the range is small.
+ */
+int pi_autotune_eval(pi_handle* h, const float* V, float* Vscratch, const int32_t* policy,
+                     const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma, void* stream);
+
+/*
  * n_sweeps evaluation sweeps ping-ponging between Va and Vb (sweep 0 reads Va and
  * writes Vb, sweep 1 reads Vb, ...) — the body of policy_evaluation's loop between
  * two host checks (:305-331, SYNC_INTERVAL = 25).  d_delta (nullable) receives the
@@ -164,7 +174,8 @@ int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, 
 /* Introspection: 0 n_states, 1 n_actions, 2 D, 3 workgroups per launch,
  * 4 VGPRs of the eval kernel, 5 VGPRs of the improve kernel, 6 compute units,
  * 7 = 1 if the last pi_compile was served from the cache, 8 VGPRs of the replay kernel,
- * 9 states per thread of the replay kernel. */
+ * 9 states per thread of the replay kernel, 10 tiled kernels loaded, 12 / 13 workgroups per CU
+ * of the evaluation / improvement sweeps, 20+d box extent, 30+d tile extent, 40+d reach. */
 int64_t pi_info(pi_handle* h, int what);
 
 #ifdef __cplusplus

@@ -475,3 +475,26 @@ def test_value_sweep_bit_exact(name, shape, cuda_device):
     assert np.array_equal(d_pol.cpu().numpy(), o_pol)
     assert np.float32(d_delta.item()) == np.float32(o_delta) and int(d_changed.item()) == o_changed
     eng.close()
+
+
+def test_autotune_changes_geometry_not_results(cuda_device):
+    """pi_autotune_eval picks a workgroups-per-CU setting by timing; whatever it picks, the sweep
+    stays bit-identical to the oracle."""
+    torch = _torch()
+    name, shape = "cartpole", (30, 30, 30, 30)
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, 9)
+    n = len(V)
+    d_V, d_pol = _dev(V, cuda_device), _dev(pol, cuda_device)
+    d_term = _dev(term.astype(np.uint8), cuda_device)
+    d_Vn = torch.empty_like(d_V)
+    picked = eng.autotune_eval(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99)
+    assert picked in (2, 3, 4, 6, 8)
+    d_Vn.fill_(float("nan"))
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99,
+                   d_delta.data_ptr())
+    torch.cuda.synchronize()
+    o_Vn, o_delta = H.oracle_for(name).eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, 0.99)
+    H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "V' after autotune")
+    assert np.float32(d_delta.item()) == np.float32(o_delta)
+    eng.close()
