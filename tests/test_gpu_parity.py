@@ -488,7 +488,7 @@ def test_autotune_changes_geometry_not_results(cuda_device):
     d_term = _dev(term.astype(np.uint8), cuda_device)
     d_Vn = torch.empty_like(d_V)
     picked = eng.autotune_eval(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99)
-    assert picked in (2, 3, 4, 6, 8)
+    assert picked in (2, 3, 4, 6, 8, 4096)
     d_Vn.fill_(float("nan"))
     d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
     eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99,
