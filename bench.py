@@ -130,7 +130,6 @@ def main() -> None:
     solver.d_policy[:n].copy_(P0)
     del V0, P0
 
-    solver.autotune()            # launch geometry for THIS V / policy (outside the timed region)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     cached = getattr(solver._backend, "_cache", None) is not None
 

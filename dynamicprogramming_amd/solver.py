@@ -494,7 +494,8 @@ class _CudaPolicyIterationBase(abc.ABC):
 
     def autotune(self) -> None:
         """Let the backend pick its launch geometry for the evaluation sweeps on the CURRENT
-        V and policy (d_new_value_function is used as scratch and restored)."""
+        V and policy (d_new_value_function is used as scratch and restored).  Optional: the default
+        geometry (one workgroup per 256-state chunk) was the fastest on every BASELINE config."""
         if hasattr(self._backend, "autotune") and self._s_end > self._s_begin:
             gamma = float(np.float32(self.config.gamma))
             self._backend.autotune(self.d_value_function, self.d_new_value_function, self.d_policy,
@@ -507,8 +508,6 @@ class _CudaPolicyIterationBase(abc.ABC):
         0, 25, 50, ... and the last one, drops below theta (:300-336)."""
         cfg = self.config
         gamma = float(np.float32(cfg.gamma))
-        if self.stats["pi_iterations"] == 1 and not getattr(self, "_tuned", False):
-            self.autotune()      # second evaluation: V and the policy now look like the real run
         delta = float("inf")
         t0 = time.perf_counter()
         i = 0
