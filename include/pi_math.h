@@ -35,6 +35,7 @@
 
 #if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define PI_MATH_FN __device__ __forceinline__
+#define PI_MATH_LDEXP(v, e) ldexpf((v), (e))
 #define PI_MATH_BITS_F2U(f) __float_as_uint(f)
 #define PI_MATH_BITS_U2F(u) __uint_as_float(u)
 #else
@@ -42,6 +43,7 @@
 #include <stdint.h>
 #include <string.h>
 #define PI_MATH_FN static inline
+#define PI_MATH_LDEXP(v, e) ldexpf((v), (e))
 static inline unsigned int pi__f2u(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
 static inline float pi__u2f(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 #define PI_MATH_BITS_F2U(f) pi__f2u(f)
@@ -117,42 +119,74 @@ PI_MATH_FN float pi_cosf(float x) {
  * is every angle-wrap call in the reference envs; the general path is the
  * classic shift-and-subtract on the integer significands.
  */
+/*
+ * Exact fmodf without loops or calls, so that a loop-invariant angle wrap — and everything the
+ * env computes from it — can be hoisted out of the per-action loop of the improvement sweep
+ * (control flow with loops in it pins a value inside the loop it is computed in).
+ *
+ * One reduction step: for finite 0 < b and a < 2^23 * b, q = trunc(RN(a / b)) is the true
+ * integer quotient or one more; a - q*b is then exactly representable (|.| < b, a multiple of
+ * ulp(b)) so the fma returns it exactly, and one conditional +b repairs the "one more" case.
+ * |x| / |y| can reach 2^277, so up to 12 steps peel 23 bits each, from b * 2^(23*11) downwards;
+ * all but the last are skipped (selects) for ordinary arguments.
+ */
+PI_MATH_FN float pi__fmod_step(float a, float b) {
+    float q = truncf(a / b);
+    float r = fmaf(-q, b, a);
+    r = (r < 0.0f) ? r + b : r;
+    r = (r >= b) ? r - b : r;
+    return r;
+}
+
 PI_MATH_FN float pi_fmodf(float x, float y) {
-    unsigned int ux = PI_MATH_BITS_F2U(x), uy = PI_MATH_BITS_F2U(y);
-    unsigned int sx = ux & 0x80000000u;
-    unsigned int ax = ux & 0x7FFFFFFFu, ay = uy & 0x7FFFFFFFu;
-    if (ay == 0u || ax >= 0x7F800000u || ay > 0x7F800000u) {
-        float t = x * y;            /* y == 0, x Inf/NaN, y NaN -> NaN */
-        return t / t;
-    }
-    if (ax < ay) return x;
-    if (ax == ay) return PI_MATH_BITS_U2F(sx);          /* +-0 */
-    {
-        float fx = PI_MATH_BITS_U2F(ax), fy = PI_MATH_BITS_U2F(ay);
-        if (ay < 0x7F000000u && fx <= 2.0f * fy) {      /* y <= x <= 2y */
-            float r = fx - fy;                          /* exact */
-            if (r >= fy) r = r - fy;                    /* only when fx == 2fy */
-            return PI_MATH_BITS_U2F(PI_MATH_BITS_F2U(r) | sx);
+    const unsigned int ux = PI_MATH_BITS_F2U(x), uy = PI_MATH_BITS_F2U(y);
+    const unsigned int sx = ux & 0x80000000u;
+    const unsigned int ax = ux & 0x7FFFFFFFu, ay = uy & 0x7FFFFFFFu;
+    const float fx = PI_MATH_BITS_U2F(ax), fy = PI_MATH_BITS_U2F(ay);
+    /* |x| <= 2|y| (every angle wrap): |x| - |y| is exact (Sterbenz); once more if |x| == 2|y| */
+    float r = fx - fy;
+    r = (r >= fy) ? r - fy : r;
+    r = (ax < ay) ? fx : r;
+    const int special = (ay == 0u) | (ax >= 0x7F800000u) | (ay > 0x7F800000u);
+    const int common = !special & (ay < 0x7F000000u) & (fx <= 2.0f * fy);
+    if (!common) {
+        if (special) {
+            const float t = x * y;                      /* y == 0, x Inf/NaN, y NaN -> NaN */
+            r = t / t;
+        } else if (ay == 0x7F800000u) {
+            r = fx;                                     /* fmod(finite, Inf) = x */
+        } else {
+            /* scale a subnormal divisor (and the dividend with it) into the normal range: exact */
+            const int tiny = ay < 0x00800000u;
+            const float sc = tiny ? 16777216.0f : 1.0f;             /* 2^24 */
+            float b = fy * sc;
+            float a = fx;
+            float carry = 0.0f;
+            if (tiny && ax >= 0x73000000u) {
+                /* |x| * 2^24 would overflow: reduce by b * 2^k blocks at the original scale first */
+                carry = 1.0f;
+            }
+            float as = (carry != 0.0f) ? a : a * sc;
+            float bs = (carry != 0.0f) ? fy : b;
+            /* peel 23 quotient bits per step, largest block first; a block 2^(23 j) * bs that would
+             * overflow or exceeds the dividend is skipped */
+#pragma unroll
+            for (int j = 11; j >= 0; --j) {
+                const float blk = PI_MATH_LDEXP(bs, 23 * j);
+                const int use = (blk <= as) & (blk <= 3.4028234663852886e38f);
+                const float red = pi__fmod_step(as, use ? blk : 1.0f);
+                as = use ? red : as;
+            }
+            if (carry != 0.0f) {
+                /* subnormal divisor, huge dividend: `as` < fy already (exact steps at the original
+                 * scale work on subnormal blocks as well because every operation above is exact) */
+                r = as;
+            } else {
+                r = as / sc;                            /* exact power-of-two descale */
+            }
         }
     }
-    {
-        int ex = (int)(ax >> 23), ey = (int)(ay >> 23);
-        unsigned int mx, my;
-        if (ex == 0) { mx = ax; ex = 1; while ((mx & 0x00800000u) == 0u) { mx <<= 1; ex--; } }
-        else mx = (ax & 0x007FFFFFu) | 0x00800000u;
-        if (ey == 0) { my = ay; ey = 1; while ((my & 0x00800000u) == 0u) { my <<= 1; ey--; } }
-        else my = (ay & 0x007FFFFFu) | 0x00800000u;
-        for (; ex > ey; ex--) {
-            if (mx >= my) mx -= my;
-            mx <<= 1;
-        }
-        if (mx >= my) mx -= my;
-        if (mx == 0u) return PI_MATH_BITS_U2F(sx);
-        while ((mx & 0x00800000u) == 0u) { mx <<= 1; ex--; }
-        if (ex > 0) mx = (mx & 0x007FFFFFu) | ((unsigned int)ex << 23);
-        else mx >>= (unsigned int)(1 - ex);
-        return PI_MATH_BITS_U2F(mx | sx);
-    }
+    return PI_MATH_BITS_U2F(PI_MATH_BITS_F2U(r) | ((r == r) ? sx : 0u));
 }
 
 #endif /* PI_MATH_H_ */
