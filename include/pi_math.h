@@ -143,50 +143,34 @@ PI_MATH_FN float pi_fmodf(float x, float y) {
     const unsigned int sx = ux & 0x80000000u;
     const unsigned int ax = ux & 0x7FFFFFFFu, ay = uy & 0x7FFFFFFFu;
     const float fx = PI_MATH_BITS_U2F(ax), fy = PI_MATH_BITS_U2F(ay);
-    /* |x| <= 2|y| (every angle wrap): |x| - |y| is exact (Sterbenz); once more if |x| == 2|y| */
+    /* common case (every angle wrap): 0 < |y| < 2^127 finite and |x| <= 2|y| (false for a NaN/Inf
+     * operand): |x| - |y| is exact (Sterbenz); subtract once more if |x| == 2|y|; |x| < |y| -> x */
+    const int common = (ay - 1u < 0x7EFFFFFFu) & (fx <= 2.0f * fy);
     float r = fx - fy;
     r = (r >= fy) ? r - fy : r;
     r = (ax < ay) ? fx : r;
-    const int special = (ay == 0u) | (ax >= 0x7F800000u) | (ay > 0x7F800000u);
-    const int common = !special & (ay < 0x7F000000u) & (fx <= 2.0f * fy);
     if (!common) {
-        if (special) {
+        if ((ay == 0u) | (ax >= 0x7F800000u) | (ay > 0x7F800000u)) {
             const float t = x * y;                      /* y == 0, x Inf/NaN, y NaN -> NaN */
-            r = t / t;
-        } else if (ay == 0x7F800000u) {
-            r = fx;                                     /* fmod(finite, Inf) = x */
-        } else {
-            /* scale a subnormal divisor (and the dividend with it) into the normal range: exact */
-            const int tiny = ay < 0x00800000u;
-            const float sc = tiny ? 16777216.0f : 1.0f;             /* 2^24 */
-            float b = fy * sc;
-            float a = fx;
-            float carry = 0.0f;
-            if (tiny && ax >= 0x73000000u) {
-                /* |x| * 2^24 would overflow: reduce by b * 2^k blocks at the original scale first */
-                carry = 1.0f;
-            }
-            float as = (carry != 0.0f) ? a : a * sc;
-            float bs = (carry != 0.0f) ? fy : b;
-            /* peel 23 quotient bits per step, largest block first; a block 2^(23 j) * bs that would
-             * overflow or exceeds the dividend is skipped */
+            return t / t;
+        }
+        if (ay == 0x7F800000u) return x;                /* fmod(finite, Inf) = x */
+        if (ax >= ay) {
+            /* peel 23 quotient bits per step, largest block first; a block |y| * 2^(23 j) that
+             * overflows or exceeds what is left is skipped (every operation is exact, subnormal
+             * divisors included) */
+            float as = fx;
 #pragma unroll
             for (int j = 11; j >= 0; --j) {
-                const float blk = PI_MATH_LDEXP(bs, 23 * j);
+                const float blk = PI_MATH_LDEXP(fy, 23 * j);
                 const int use = (blk <= as) & (blk <= 3.4028234663852886e38f);
                 const float red = pi__fmod_step(as, use ? blk : 1.0f);
                 as = use ? red : as;
             }
-            if (carry != 0.0f) {
-                /* subnormal divisor, huge dividend: `as` < fy already (exact steps at the original
-                 * scale work on subnormal blocks as well because every operation above is exact) */
-                r = as;
-            } else {
-                r = as / sc;                            /* exact power-of-two descale */
-            }
+            r = as;
         }
     }
-    return PI_MATH_BITS_U2F(PI_MATH_BITS_F2U(r) | ((r == r) ? sx : 0u));
+    return PI_MATH_BITS_U2F(PI_MATH_BITS_F2U(r) | sx);
 }
 
 #endif /* PI_MATH_H_ */
