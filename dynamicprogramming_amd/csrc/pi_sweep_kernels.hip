@@ -33,6 +33,24 @@
 
 #define PI_C (1 << PI_D)
 #define PI_BLOCK 256
+// Optional occupancy targets (waves per SIMD) for the two hot kernels; 0 = let the compiler
+// decide.  Second argument of __launch_bounds__ on AMD = minimum waves per SIMD (EU).
+#ifndef PI_EVAL_MIN_WAVES
+#define PI_EVAL_MIN_WAVES 0
+#endif
+#ifndef PI_IMPROVE_MIN_WAVES
+#define PI_IMPROVE_MIN_WAVES 0
+#endif
+#if PI_EVAL_MIN_WAVES > 0
+#define PI_LB_EVAL __launch_bounds__(PI_BLOCK, PI_EVAL_MIN_WAVES)
+#else
+#define PI_LB_EVAL __launch_bounds__(PI_BLOCK)
+#endif
+#if PI_IMPROVE_MIN_WAVES > 0
+#define PI_LB_IMPROVE __launch_bounds__(PI_BLOCK, PI_IMPROVE_MIN_WAVES)
+#else
+#define PI_LB_IMPROVE __launch_bounds__(PI_BLOCK)
+#endif
 #define PI_NXCD 8
 
 // ---- compile-time grid geometry ------------------------------------------------
@@ -316,7 +334,7 @@ __device__ __forceinline__ void pi_eval_body(const float* __restrict__ V, float*
     if (delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
 }
 
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void PI_LB_EVAL
 pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
                      const int* __restrict__ policy, const unsigned char* __restrict__ term,
                      const float* __restrict__ tab, long long s_begin, long long s_end,
@@ -506,7 +524,7 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
     if (WRITE_V && delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
 }
 
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void PI_LB_IMPROVE
 pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
                         const unsigned char* __restrict__ term, const float* __restrict__ tab,
                         long long s_begin, long long s_end, float gamma,
@@ -514,7 +532,7 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
     pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed);
 }
 
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void PI_LB_IMPROVE
 pi_value_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn, int* __restrict__ policy,
                       const unsigned char* __restrict__ term, const float* __restrict__ tab,
                       long long s_begin, long long s_end, float gamma,

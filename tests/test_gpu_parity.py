@@ -498,3 +498,66 @@ def test_autotune_changes_geometry_not_results(cuda_device):
     H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "V' after autotune")
     assert np.float32(d_delta.item()) == np.float32(o_delta)
     eng.close()
+
+
+def test_full_size_c5_properties(cuda_device, kernel_family):
+    """BASELINE config C5 (double cartpole 25^6 = 244 140 625 states, n odd) at full size on one
+    GPU: residual, shard invariance with the ragged 8-way split the multi-GPU path uses, terminal
+    states copied, oracle windows (64-corner interpolation, int32 indices near 2^28)."""
+    if kernel_family == "tiled":
+        pytest.skip("full-size 6-D check runs on the default (flat) kernels")
+    torch = _torch()
+    name, shape = "double_cartpole", (25,) * 6
+    eng, bins, acts = _engine(name, shape, cuda_device)
+    n = 25 ** 6
+    gamma = float(np.float32(0.999))
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    V = torch.randn(n, generator=gen, dtype=torch.float32)
+    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
+    # terminal mask from the bin tables (|x| > 2.4 or |theta| > 20 deg), without the (n, 6) array
+    lim = envs.DoubleCartPoleCuda._TH_FAIL
+    bad = [np.abs(bins[0]) > 2.4, np.zeros(25, bool), np.abs(bins[2]) > lim, np.zeros(25, bool),
+           np.abs(bins[4]) > lim, np.zeros(25, bool)]
+    term = torch.zeros(shape, dtype=torch.bool)
+    for d, b in enumerate(bad):
+        view = [1] * 6
+        view[d] = 25
+        term |= torch.from_numpy(b).view(view)
+    term = term.reshape(-1).to(torch.uint8)
+    d_V, d_pol, d_term = V.to(cuda_device), pol.to(cuda_device), term.to(cuda_device)
+    d_Vn = torch.empty_like(d_V)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                   d_delta.data_ptr())
+    torch.cuda.synchronize()
+    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
+    tmask = d_term.bool()
+    assert torch.equal(d_Vn[tmask], d_V[tmask]) and int(tmask.sum()) > 0
+    per = -(-n // 8)
+    d_Vs = torch.empty_like(d_V)
+    for r in range(8):
+        a, b = min(r * per, n), min((r + 1) * per, n)
+        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_Vs, d_Vn)
+    chk = H.oracle_for(name)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    Vh, polh, termh = V.numpy(), pol.numpy(), term.numpy()
+    Vn_h = d_Vn.cpu().numpy()
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    for a, b in [(0, 2048), (n // 2 - 1500, n // 2 + 1500), (n - 2048, n)]:
+        sub = np.arange(a, b)
+        idx = np.stack(np.unravel_index(sub, shape), axis=1)
+        pad_states = np.zeros((b, 6), dtype=np.float32)          # only rows [a, b) are touched
+        pad_states[a:b] = np.stack([bins[d][idx[:, d]] for d in range(6)], axis=1)
+        o_Vn = np.zeros(b, dtype=np.float32)
+        chk.eval_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape, strides, gamma, a, b,
+                       out=o_Vn)
+        H.assert_bits_equal(Vn_h[a:b], o_Vn[a:b], f"C5 eval window [{a},{b})")
+        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
+                          d_changed.data_ptr())
+        o_pol, o_changed = chk.improve_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape,
+                                             strides, gamma, a, b)
+        assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
+        assert int(d_changed.item()) == o_changed
+    eng.close()
