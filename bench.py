@@ -96,7 +96,8 @@ def main() -> None:
     ap.add_argument("--transition-cache", action="store_true",
                     help="record transitions on the first evaluation sweep of a step and replay them "
                          "on the others (default: recompute the dynamics every sweep, as the reference)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 22)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23,
+                    help="states of the same grid the CPU baseline sweeps (about 15 CPU-seconds)")
     args = ap.parse_args()
 
     import torch
