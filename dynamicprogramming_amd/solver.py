@@ -411,6 +411,16 @@ class _CudaPolicyIterationBase(abc.ABC):
             self._interior_ranges = interior
             self._d_delta_parts = torch.zeros(len(merged) + len(interior) + 1, dtype=torch.float32,
                                               device=dev)
+        # Debug aid (tests): PI_MI355_POISON_UNREACHED=1 overwrites, after every exchange, all of
+        # V' that this rank neither owns nor declared reachable with NaN — a read outside the
+        # planned band then poisons the result instead of silently using stale data.
+        self._poison = None
+        if os.environ.get("PI_MI355_POISON_UNREACHED") == "1":
+            keep = torch.zeros(self._n_pad, dtype=torch.bool, device=dev)
+            keep[self._s_begin:self._s_end] = True
+            for p in np.flatnonzero(mine):
+                keep[int(p) * stride0:min((int(p) + 1) * stride0, n)] = True
+            self._poison = ~keep
         logger.info(f"halo exchange: rank {self._rank} receives {recv[self._rank] * 4 / 2**20:.1f} MiB "
                     f"per sweep instead of {full * 4 / 2**20:.1f} MiB")
 
@@ -432,6 +442,8 @@ class _CudaPolicyIterationBase(abc.ABC):
             return
         for req in self._start_exchange(full):
             req.wait()
+        if getattr(self, "_poison", None) is not None and full.dtype.is_floating_point:
+            full[self._poison] = float("nan")
 
     def _all_reduce_scalar(self, t, op) -> None:
         import torch.distributed as dist
@@ -471,6 +483,8 @@ class _CudaPolicyIterationBase(abc.ABC):
                     i += 1
                 for req in reqs:
                     req.wait()
+                if self._poison is not None:
+                    self.d_new_value_function[self._poison] = float("nan")
                 if last:
                     self._d_delta.copy_(parts[:i].max().reshape(1))
             else:

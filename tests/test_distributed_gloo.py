@@ -29,6 +29,7 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
     sys.path.insert(0, str(ROOT))
     import os
     os.environ["PI_MI355_EXCHANGE"] = exchange
+    os.environ["PI_MI355_POISON_UNREACHED"] = "1"     # reads outside the planned band -> NaN
     import torch
     import torch.distributed as dist
     from dynamicprogramming_amd import envs
