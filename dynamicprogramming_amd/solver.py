@@ -486,7 +486,10 @@ class _CudaPolicyIterationBase(abc.ABC):
                 if self._poison is not None:
                     self.d_new_value_function[self._poison] = float("nan")
                 if last:
-                    self._d_delta.copy_(parts[:i].max().reshape(1))
+                    if i:
+                        self._d_delta.copy_(parts[:i].max().reshape(1))
+                    else:
+                        self._d_delta.zero_()          # empty shard
             else:
                 self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
                                           self.d_policy, self.d_terminal_mask, self._s_begin,
