@@ -561,3 +561,27 @@ def test_full_size_c5_properties(cuda_device, kernel_family):
         assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
         assert int(d_changed.item()) == o_changed
     eng.close()
+
+
+@pytest.mark.parametrize("name,bins", [("double_pendulum_swingup", 15), ("double_cartpole", 7)])
+def test_full_run_4d_6d_matches_oracle(name, bins, cuda_device, kernel_family):
+    """End-to-end run() with the env's own settings on a 4-D grid (15^4, the reference runner's
+    default; ~66 000 sweeps of wrap- and trig-heavy dynamics) and a 6-D grid: V, policy and the
+    sweep count of every outer iteration equal the oracle's run."""
+    if kernel_family == "tiled":
+        pytest.skip("long run: default kernel family only")
+    cls = envs.ENVS[name]
+    cfg = envs.CudaPIConfig(**cls.CONFIG)
+    solver = envs.make(name, bins, device=cuda_device)
+    solver.run()
+    tables = H.env_bins(name, (bins,) * cls._D)
+    lo, hi, gshape, strides = oracle.grid_metadata(tables)
+    states = oracle.states_from_bins(tables)
+    term, tval = H.terminal_mask(name, states)
+    ref = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, gamma=cfg.gamma,
+                                 theta=cfg.theta, max_eval_iter=cfg.max_eval_iter,
+                                 max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
+    assert solver.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
+    assert solver.stats.get("stable") == ref["stable"]
+    assert np.array_equal(solver.policy, ref["policy"])
+    H.assert_bits_equal(solver.value_function, ref["value_function"], f"{name} full run V")
