@@ -34,25 +34,37 @@ SIGNATURES = {
     "pi_kernel_source": (ctypes.c_size_t, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]),
     "pi_eval_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_float, _vp, _vp]),
-    "pi_autotune_eval": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.c_float, _vp]),
     "pi_eval_sweeps": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, ctypes.c_int, _vp, _vp]),
-    "pi_transition_cache_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int64, ctypes.c_int64]),
-    "pi_eval_sweeps_cached": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
-                                             ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp,
-                                             ctypes.c_size_t, _vp, _vp]),
     "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, _vp, _vp]),
     "pi_value_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, _vp, _vp, _vp]),
-    "pi_reach_planes": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp]),
+    "pi_reach_planes": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    "pi_comm_unique_id": (ctypes.c_int, [_vp]),
+    "pi_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "pi_comm_init_local": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "pi_comm_destroy": (ctypes.c_int, [_vp]),
+    "pi_comm_info": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "pi_allgather_V": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
+    "pi_allgather_policy": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
+    "pi_allreduce_max_f32": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_allreduce_sum_u32": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_plan_segments": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int64, _vp, _vp, ctypes.c_int64]),
+    "pi_exchange_plan": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "pi_exchange_V": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_eval_sweeps_sharded": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int,
+                                              _vp, _vp]),
+    "pi_improve_sweep_sharded": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "pi_probe_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
     "pi_probe_interp": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "pi_probe_coords": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, _vp]),
+    "pi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 _load_error: Exception | None = None
 
@@ -109,6 +121,27 @@ def _check(rc: int, what: str) -> None:
         raise NativeError(f"{what} failed: {last_error()}")
 
 
+def comm_unique_id() -> bytes:
+    """A fresh 128-byte RCCL id (create on one rank, hand to every rank's `Engine.comm_init`)."""
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().pi_comm_unique_id(buf), "pi_comm_unique_id")
+    return buf.raw
+
+
+def plan_segments(world, g0, stride0, n_states, per, reach) -> np.ndarray:
+    """Host-only planner of the halo exchange (pi_plan_segments): reach is a (world, g0) bool
+    array; returns an (m, 4) int64 array of {src, dst, a, b}."""
+    r = np.ascontiguousarray(reach, dtype=np.uint8)
+    assert r.shape == (world, g0)
+    fn = lib().pi_plan_segments
+    m = fn(world, g0, stride0, n_states, per, r.ctypes.data_as(_vp), None, 0)
+    if m < 0:
+        raise NativeError(f"pi_plan_segments failed: {last_error()}")
+    out = np.zeros((max(int(m), 1), 4), dtype=np.int64)
+    fn(world, g0, stride0, n_states, per, r.ctypes.data_as(_vp), out.ctypes.data_as(_vp), int(m))
+    return out[: int(m)]
+
+
 class Engine:
     """One pi_handle: a grid + action set + (after compile) its specialised kernels."""
 
@@ -160,23 +193,9 @@ class Engine:
         _check(lib().pi_eval_sweep(self._h, V, Vnew, policy, term, s_begin, s_end, gamma,
                                    d_delta or None, stream or None), "pi_eval_sweep")
 
-    def autotune_eval(self, V, Vscratch, policy, term, s_begin, s_end, gamma, stream=0):
-        _check(lib().pi_autotune_eval(self._h, V, Vscratch, policy, term, s_begin, s_end, gamma,
-                                      stream or None), "pi_autotune_eval")
-        return self.info(12)
-
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta=0, stream=0):
         _check(lib().pi_eval_sweeps(self._h, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps,
                                     d_delta or None, stream or None), "pi_eval_sweeps")
-
-    def transition_cache_bytes(self, s_begin, s_end) -> int:
-        return int(lib().pi_transition_cache_bytes(self._h, s_begin, s_end))
-
-    def eval_sweeps_cached(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, rebuild,
-                           cache, cache_bytes, d_delta=0, stream=0):
-        _check(lib().pi_eval_sweeps_cached(self._h, Va, Vb, policy, term, s_begin, s_end, gamma,
-                                           n_sweeps, int(bool(rebuild)), cache, cache_bytes,
-                                           d_delta or None, stream or None), "pi_eval_sweeps_cached")
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
         _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,
@@ -186,9 +205,63 @@ class Engine:
         _check(lib().pi_value_sweep(self._h, V, Vnew, policy, term, s_begin, s_end, gamma,
                                     d_delta or None, d_changed or None, stream or None), "pi_value_sweep")
 
-    def reach_planes(self, term, s_begin, s_end, d_bitmap, stream=0):
-        _check(lib().pi_reach_planes(self._h, term, s_begin, s_end, d_bitmap, stream or None),
+    def reach_planes(self, term, s_begin, s_end, d_bitmap, stream=0, dim=0):
+        _check(lib().pi_reach_planes(self._h, term, s_begin, s_end, int(dim), d_bitmap, stream or None),
                "pi_reach_planes")
+
+    def probe_coords(self, s_begin, s_end, out, chunks_per_workgroup=1, stream=0):
+        _check(lib().pi_probe_coords(self._h, s_begin, s_end, out, int(chunks_per_workgroup),
+                                     stream or None), "pi_probe_coords")
+
+    def set_option(self, what: int, value: int) -> None:
+        _check(lib().pi_set_option(self._h, int(what), int(value)), "pi_set_option")
+
+    # -- multi-GPU (RCCL or the in-process test transport) ---------------------
+    def comm_init(self, rank: int, world: int, unique_id: bytes) -> None:
+        assert len(unique_id) == 128
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _check(lib().pi_comm_init(self._h, int(rank), int(world), buf), "pi_comm_init")
+
+    def comm_init_local(self, rank: int, world: int, group: str) -> None:
+        _check(lib().pi_comm_init_local(self._h, int(rank), int(world), group.encode()),
+               "pi_comm_init_local")
+
+    def comm_destroy(self) -> None:
+        _check(lib().pi_comm_destroy(self._h), "pi_comm_destroy")
+
+    def comm_info(self, what: int) -> int:
+        return int(lib().pi_comm_info(self._h, int(what)))
+
+    def allgather_V(self, V_full, shard_elems, stream=0):
+        _check(lib().pi_allgather_V(self._h, V_full, shard_elems, stream or None), "pi_allgather_V")
+
+    def allgather_policy(self, policy_full, shard_elems, stream=0):
+        _check(lib().pi_allgather_policy(self._h, policy_full, shard_elems, stream or None),
+               "pi_allgather_policy")
+
+    def allreduce_max_f32(self, d_value, stream=0):
+        _check(lib().pi_allreduce_max_f32(self._h, d_value, stream or None), "pi_allreduce_max_f32")
+
+    def allreduce_sum_u32(self, d_value, stream=0):
+        _check(lib().pi_allreduce_sum_u32(self._h, d_value, stream or None), "pi_allreduce_sum_u32")
+
+    def exchange_plan(self, term, per, mode=0, overlap=True, stream=0):
+        info = (ctypes.c_int64 * 5)()
+        _check(lib().pi_exchange_plan(self._h, term, int(per), int(mode), int(bool(overlap)), info,
+                                      stream or None), "pi_exchange_plan")
+        return {"mode": "halo" if info[0] == 2 else "allgather", "recv_elems": int(info[1]),
+                "send_elems": int(info[2]), "send_ranges": int(info[3]), "interior_ranges": int(info[4])}
+
+    def exchange_V(self, V_full, stream=0):
+        _check(lib().pi_exchange_V(self._h, V_full, stream or None), "pi_exchange_V")
+
+    def eval_sweeps_sharded(self, Va, Vb, policy, term, gamma, n_sweeps, d_delta=0, stream=0):
+        _check(lib().pi_eval_sweeps_sharded(self._h, Va, Vb, policy, term, gamma, n_sweeps,
+                                            d_delta or None, stream or None), "pi_eval_sweeps_sharded")
+
+    def improve_sweep_sharded(self, V, policy, term, gamma, d_changed=0, stream=0):
+        _check(lib().pi_improve_sweep_sharded(self._h, V, policy, term, gamma, d_changed or None,
+                                              stream or None), "pi_improve_sweep_sharded")
 
     def probe_step(self, states, acts, nxt, reward, done, m, stream=0):
         _check(lib().pi_probe_step(self._h, states, acts, nxt, reward, done, m, stream or None),

@@ -1,0 +1,589 @@
+// pi_comm.cpp — the multi-GPU half of libpi_mi355.so: transports, the exchange plan and the
+// sharded sweep driver (SURVEY.md section 8e / 8b "must export": pi_comm_init, pi_allgather_V,
+// pi_allreduce_*).  The reference has no counterpart: src/cuda_policy_iteration.py:300-336 is a
+// single-device loop.
+//
+// Partition: contiguous flat-index shards of `per` = ceil(n / world) states (slabs along
+// dimension 0); every rank keeps a full-size V, sweeps its shard and then makes the new values
+// visible where other ranks will read them, either
+//   * halo exchange — exactly the dimension-0 plane runs each peer can reach (measured once for
+//     ALL actions with pi_reach_planes_kernel), as grouped ncclSend/ncclRecv in place in V', the
+//     planes peers wait for swept first and sent on a second HIP stream while the interior is
+//     swept; or
+//   * all-gather of the shards (ncclAllGather, in place) when the reachable bands cover most
+//     of the grid anyway.
+// Two transports implement the same small interface: RCCL (one process per GPU, xGMI), and an
+// in-process one (several handles of ONE process, one host thread each, device-to-device copies
+// ordered by HIP events) that exists so the stream ordering of the overlapped exchange can be
+// tested with real kernels on a single GPU.
+
+#include "pi_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+
+using pi::fail;
+
+namespace pi {
+
+struct Comm {
+    int rank = 0, world = 1;
+    virtual ~Comm() {}
+    virtual const char* kind() const = 0;
+    virtual int group_begin() = 0;
+    virtual int send(const void* p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int recv(void* p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int group_end(hipStream_t st) = 0;
+    // every rank contributes `bytes` at full + rank * bytes; afterwards all ranks hold all
+    virtual int allgather(void* full, size_t bytes, hipStream_t st) = 0;
+    virtual int allreduce_max_f32(float* d, hipStream_t st) = 0;
+    virtual int allreduce_sum_u32(uint32_t* d, hipStream_t st) = 0;
+};
+
+struct ShardPlan {
+    int64_t per = 0, s_begin = 0, s_end = 0;
+    bool halo = false;
+    struct Seg { int src, dst; int64_t a, b; };
+    std::vector<Seg> segs;                                   // only those that involve this rank
+    std::vector<std::pair<int64_t, int64_t>> send_ranges, interior;
+    int64_t recv_elems = 0, send_elems = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    ~ShardPlan() {
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    }
+};
+
+void drop_plan(pi_handle* h) {
+    delete h->plan;
+    h->plan = nullptr;
+}
+void release_comm(pi_handle* h) {
+    drop_plan(h);
+    delete h->comm;
+    h->comm = nullptr;
+}
+
+}  // namespace pi
+
+namespace {
+
+#define PI_NCCL(expr)                                                                      \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess)                                                             \
+            return fail(std::string(#expr) + ": " + ncclGetErrorString(r_));               \
+    } while (0)
+
+// ---- RCCL ------------------------------------------------------------------------------
+struct RcclComm : pi::Comm {
+    ncclComm_t comm = nullptr;
+    ~RcclComm() override {
+        if (comm) (void)ncclCommDestroy(comm);
+    }
+    const char* kind() const override { return "rccl"; }
+    int group_begin() override { PI_NCCL(ncclGroupStart()); return 0; }
+    int send(const void* p, size_t bytes, int peer, hipStream_t st) override {
+        PI_NCCL(ncclSend(p, bytes, ncclChar, peer, comm, st));
+        return 0;
+    }
+    int recv(void* p, size_t bytes, int peer, hipStream_t st) override {
+        PI_NCCL(ncclRecv(p, bytes, ncclChar, peer, comm, st));
+        return 0;
+    }
+    int group_end(hipStream_t) override { PI_NCCL(ncclGroupEnd()); return 0; }
+    int allgather(void* full, size_t bytes, hipStream_t st) override {
+        PI_NCCL(ncclAllGather(static_cast<const char*>(full) + (size_t)rank * bytes, full, bytes, ncclChar,
+                              comm, st));
+        return 0;
+    }
+    int allreduce_max_f32(float* d, hipStream_t st) override {
+        PI_NCCL(ncclAllReduce(d, d, 1, ncclFloat, ncclMax, comm, st));
+        return 0;
+    }
+    int allreduce_sum_u32(uint32_t* d, hipStream_t st) override {
+        PI_NCCL(ncclAllReduce(d, d, 1, ncclUint32, ncclSum, comm, st));
+        return 0;
+    }
+};
+
+// ---- in-process transport (test transport: N handles, N host threads, one process) -------
+// send(): records an event on the sender's stream and posts {pointer, bytes, event} in the
+// mailbox of the (src, dst) pair.  recv() (deferred to group_end): waits on the host for the
+// posting, makes the receiver's stream wait for the sender's event, enqueues the device copy and
+// records a completion event.  group_end() finally makes the SENDER's stream wait for those
+// completion events, so a later kernel cannot overwrite a buffer that is still being copied —
+// the same stream semantics an RCCL send has.
+struct LocalGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, joined = 0, left = 0;
+    struct Msg {
+        const void* src = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool copied = false;
+    };
+    std::vector<std::deque<std::shared_ptr<Msg>>> box;        // [src * world + dst]
+    // host-side scalar reductions
+    std::vector<double> red;
+    int red_arrived = 0, red_epoch = 0;
+    double red_result = 0.0;
+};
+std::mutex g_groups_mu;
+std::map<std::string, std::shared_ptr<LocalGroup>> g_groups;
+
+struct LocalComm : pi::Comm {
+    std::shared_ptr<LocalGroup> grp;
+    std::string name;
+    struct PendingRecv { void* p; size_t bytes; int peer; hipStream_t st; };
+    std::vector<PendingRecv> recvs;
+    std::vector<std::shared_ptr<LocalGroup::Msg>> sent, retired;
+    void drop_retired() {
+        for (auto& m : retired) {
+            (void)hipEventDestroy(m->ready);
+            (void)hipEventDestroy(m->done);
+        }
+        retired.clear();
+    }
+    ~LocalComm() override {
+        (void)hipDeviceSynchronize();
+        drop_retired();
+        std::lock_guard<std::mutex> lk(g_groups_mu);
+        if (grp && ++grp->left == grp->world) g_groups.erase(name);
+    }
+    const char* kind() const override { return "local"; }
+    int group_begin() override { return 0; }
+    int send(const void* p, size_t bytes, int peer, hipStream_t st) override {
+        auto m = std::make_shared<LocalGroup::Msg>();
+        m->src = p;
+        m->bytes = bytes;
+        PI_HIP(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+        PI_HIP(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
+        PI_HIP(hipEventRecord(m->ready, st));
+        {
+            std::lock_guard<std::mutex> lk(grp->mu);
+            grp->box[(size_t)rank * world + peer].push_back(m);
+        }
+        grp->cv.notify_all();
+        sent.push_back(m);
+        return 0;
+    }
+    int recv(void* p, size_t bytes, int peer, hipStream_t st) override {
+        recvs.push_back({p, bytes, peer, st});
+        return 0;
+    }
+    int group_end(hipStream_t st) override {
+        for (const PendingRecv& r : recvs) {
+            std::shared_ptr<LocalGroup::Msg> m;
+            {
+                std::unique_lock<std::mutex> lk(grp->mu);
+                auto& q = grp->box[(size_t)r.peer * world + rank];
+                grp->cv.wait(lk, [&] { return !q.empty(); });
+                m = q.front();
+                q.pop_front();
+            }
+            if (m->bytes != r.bytes) return fail("local transport: send/recv size mismatch");
+            PI_HIP(hipStreamWaitEvent(r.st, m->ready, 0));
+            PI_HIP(hipMemcpyAsync(r.p, m->src, r.bytes, hipMemcpyDeviceToDevice, r.st));
+            PI_HIP(hipEventRecord(m->done, r.st));
+            {
+                std::lock_guard<std::mutex> lk(grp->mu);
+                m->copied = true;
+            }
+            grp->cv.notify_all();
+        }
+        recvs.clear();
+        for (auto& m : sent) {
+            {
+                std::unique_lock<std::mutex> lk(grp->mu);
+                grp->cv.wait(lk, [&] { return m->copied; });
+            }
+            PI_HIP(hipStreamWaitEvent(st, m->done, 0));
+        }
+        // both streams have enqueued their waits; the events are destroyed in batches, after a
+        // synchronisation, so none is released while a stream still refers to it
+        for (auto& m : sent) retired.push_back(m);
+        sent.clear();
+        if (retired.size() >= 512) {
+            PI_HIP(hipDeviceSynchronize());
+            drop_retired();
+        }
+        return 0;
+    }
+    int allgather(void* full, size_t bytes, hipStream_t st) override {
+        for (int p = 0; p < world; ++p)
+            if (p != rank && send(static_cast<const char*>(full) + (size_t)rank * bytes, bytes, p, st)) return 1;
+        for (int p = 0; p < world; ++p)
+            if (p != rank && recv(static_cast<char*>(full) + (size_t)p * bytes, bytes, p, st)) return 1;
+        return group_end(st);
+    }
+    // scalar reductions go through the host (this transport only exists for tests)
+    int reduce_host(double mine, bool is_max, double* out) {
+        std::unique_lock<std::mutex> lk(grp->mu);
+        const int epoch = grp->red_epoch;
+        grp->red.push_back(mine);
+        if (++grp->red_arrived == world) {
+            double r = is_max ? grp->red[0] : 0.0;
+            for (double v : grp->red) r = is_max ? std::max(r, v) : r + v;
+            grp->red_result = r;
+            grp->red_arrived = 0;
+            grp->red.clear();
+            ++grp->red_epoch;
+            grp->cv.notify_all();
+        } else {
+            grp->cv.wait(lk, [&] { return grp->red_epoch != epoch; });
+        }
+        *out = grp->red_result;
+        return 0;
+    }
+    int allreduce_max_f32(float* d, hipStream_t st) override {
+        float v;
+        PI_HIP(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, st));
+        PI_HIP(hipStreamSynchronize(st));
+        double r;
+        reduce_host((double)v, true, &r);
+        v = (float)r;
+        PI_HIP(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st));
+        PI_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    int allreduce_sum_u32(uint32_t* d, hipStream_t st) override {
+        uint32_t v;
+        PI_HIP(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, st));
+        PI_HIP(hipStreamSynchronize(st));
+        double r;
+        reduce_host((double)v, false, &r);
+        v = (uint32_t)r;
+        PI_HIP(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st));
+        PI_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+};
+
+int need_comm(pi_handle* h) {
+    if (pi::check_ready(h)) return 1;
+    if (!h->comm) return fail("no communicator on this handle: call pi_comm_init first");
+    return 0;
+}
+int need_plan(pi_handle* h) {
+    if (need_comm(h)) return 1;
+    if (!h->plan) return fail("no exchange plan on this handle: call pi_exchange_plan first");
+    return 0;
+}
+
+// Post the halo sends/receives of one freshly swept buffer on `st` (one transport group).
+int post_exchange(pi_handle* h, float* full, hipStream_t st) {
+    pi::Comm* c = h->comm;
+    const pi::ShardPlan* p = h->plan;
+    if (c->group_begin()) return 1;
+    for (const auto& s : p->segs) {
+        const size_t bytes = (size_t)(s.b - s.a) * sizeof(float);
+        if (s.src == c->rank) { if (c->send(full + s.a, bytes, s.dst, st)) return 1; }
+        else if (c->recv(full + s.a, bytes, s.src, st)) return 1;
+    }
+    return c->group_end(st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pi_comm_unique_id(void* id128) {
+    if (!id128) return fail("null argument");
+    ncclUniqueId id;
+    PI_NCCL(ncclGetUniqueId(&id));
+    static_assert(sizeof id == 128, "RCCL unique id is 128 bytes");
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int pi_comm_init(pi_handle* h, int rank, int world, const void* id128) {
+    if (!h || !id128) return fail("null argument");
+    if (h->device < 0) return fail("host-only handle cannot own a communicator");
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank/world out of range");
+    pi::DeviceGuard guard(h->device);
+    std::unique_ptr<RcclComm> c(new RcclComm);
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    PI_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    pi::release_comm(h);
+    h->comm = c.release();
+    return 0;
+}
+
+int pi_comm_init_local(pi_handle* h, int rank, int world, const char* group_name) {
+    if (!h || !group_name) return fail("null argument");
+    if (h->device < 0) return fail("host-only handle cannot own a communicator");
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank/world out of range");
+    std::unique_ptr<LocalComm> c(new LocalComm);
+    c->rank = rank;
+    c->world = world;
+    c->name = group_name;
+    {
+        std::lock_guard<std::mutex> lk(g_groups_mu);
+        auto& g = g_groups[c->name];
+        if (!g) {
+            g = std::make_shared<LocalGroup>();
+            g->world = world;
+            g->box.resize((size_t)world * world);
+        }
+        if (g->world != world) return fail("local group exists with a different world size");
+        ++g->joined;
+        c->grp = g;
+    }
+    pi::release_comm(h);
+    h->comm = c.release();
+    return 0;
+}
+
+int pi_comm_destroy(pi_handle* h) {
+    if (!h) return fail("null handle");
+    pi::DeviceGuard guard(h->device);
+    pi::release_comm(h);
+    return 0;
+}
+
+int pi_comm_info(pi_handle* h, int what) {
+    if (!h || !h->comm) return -1;
+    switch (what) {
+        case 0: return h->comm->rank;
+        case 1: return h->comm->world;
+        case 2: return std::strcmp(h->comm->kind(), "rccl") == 0 ? 1 : 2;
+        case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
+        default: return -1;
+    }
+}
+
+int pi_allgather_V(pi_handle* h, float* V_full, int64_t shard_elems, void* stream) {
+    if (need_comm(h)) return 1;
+    if (!V_full || shard_elems < 0) return fail("bad argument");
+    pi::DeviceGuard guard(h->device);
+    return h->comm->allgather(V_full, (size_t)shard_elems * sizeof(float), (hipStream_t)stream);
+}
+
+int pi_allgather_policy(pi_handle* h, int32_t* policy_full, int64_t shard_elems, void* stream) {
+    if (need_comm(h)) return 1;
+    if (!policy_full || shard_elems < 0) return fail("bad argument");
+    pi::DeviceGuard guard(h->device);
+    return h->comm->allgather(policy_full, (size_t)shard_elems * sizeof(int32_t), (hipStream_t)stream);
+}
+
+int pi_allreduce_max_f32(pi_handle* h, float* d_value, void* stream) {
+    if (need_comm(h)) return 1;
+    pi::DeviceGuard guard(h->device);
+    return h->comm->allreduce_max_f32(d_value, (hipStream_t)stream);
+}
+
+int pi_allreduce_sum_u32(pi_handle* h, uint32_t* d_value, void* stream) {
+    if (need_comm(h)) return 1;
+    pi::DeviceGuard guard(h->device);
+    return h->comm->allreduce_sum_u32(d_value, (hipStream_t)stream);
+}
+
+// Pure host logic (no GPU, no communicator): which pieces of V' must travel between ranks.
+//   reach[r * g0 + p] != 0  <=>  rank r's shard can read dimension-0 plane p (any action)
+// Output: up to `cap` segments {src, dst, a, b} = "src sends V'[a, b) to dst" (every rank derives
+// the same list from the same bitmaps).  Returns the number of segments (may exceed cap: call
+// again with a larger buffer), or -1 on bad arguments.
+int64_t pi_plan_segments(int world, int64_t g0, int64_t stride0, int64_t n_states, int64_t per,
+                         const uint8_t* reach, int64_t* segs, int64_t cap) {
+    if (world < 1 || g0 < 1 || stride0 < 1 || per < 1 || !reach) { fail("bad argument"); return -1; }
+    int64_t count = 0;
+    for (int dst = 0; dst < world; ++dst) {
+        const uint8_t* need = reach + (size_t)dst * g0;
+        int64_t p = 0;
+        while (p < g0) {
+            if (!need[p]) { ++p; continue; }
+            int64_t q = p;
+            while (q < g0 && need[q]) ++q;
+            const int64_t lo = p * stride0, hi = std::min(q * stride0, n_states);
+            for (int src = 0; src < world; ++src) {
+                const int64_t a = std::max(lo, (int64_t)src * per);
+                const int64_t b = std::min(hi, std::min(((int64_t)src + 1) * per, n_states));
+                if (src != dst && a < b) {
+                    if (segs && count < cap) {
+                        segs[4 * count + 0] = src;
+                        segs[4 * count + 1] = dst;
+                        segs[4 * count + 2] = a;
+                        segs[4 * count + 3] = b;
+                    }
+                    ++count;
+                }
+            }
+            p = q;
+        }
+    }
+    return count;
+}
+
+// mode: 0 = choose (halo unless a rank would receive > 60 % of an all-gather), 1 = all-gather,
+// 2 = halo.  `overlap` = 0 disables the send-first / interior-while-travelling split.
+// info[0] = mode chosen (1 all-gather, 2 halo), info[1] = elements this rank receives per sweep,
+// info[2] = elements it sends, info[3] = number of send ranges, info[4] = interior ranges.
+int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, int overlap,
+                     int64_t* info, void* stream) {
+    if (need_comm(h)) return 1;
+    if (!term || per < 1) return fail("bad argument");
+    pi::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    pi::Comm* c = h->comm;
+    const int64_t n = h->n_states, g0 = h->shape[0], stride0 = n / g0;
+    if (per * c->world < n) return fail("per * world < n_states");
+    std::unique_ptr<pi::ShardPlan> plan(new pi::ShardPlan);
+    plan->per = per;
+    plan->s_begin = std::min((int64_t)c->rank * per, n);
+    plan->s_end = std::min(plan->s_begin + per, n);
+    if (mode != 1) {
+        // reach bitmap of this shard -> bytes -> all ranks
+        const size_t words = (size_t)(g0 + 31) / 32;
+        uint32_t* d_bits = nullptr;
+        uint8_t* d_all = nullptr;
+        PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
+        std::vector<uint32_t> bits(words, 0u);
+        int rc = pi_reach_planes(h, term, plan->s_begin, plan->s_end, 0, d_bits, stream);
+        if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+        (void)hipFree(d_bits);
+        if (rc) return fail("reach probe failed: " + pi::last_error());
+        const size_t row = (size_t)(g0 + 3) / 4 * 4;             // padded to whole words for the transport
+        std::vector<uint8_t> all((size_t)c->world * row, 0);
+        for (int64_t p = 0; p < g0; ++p) all[(size_t)c->rank * row + p] = (bits[p >> 5] >> (p & 31)) & 1u;
+        PI_HIP(hipMalloc((void**)&d_all, all.size()));
+        hipError_t e = hipMemcpyAsync(d_all, all.data(), all.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) rc = c->allgather(d_all, row, st);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+        (void)hipFree(d_all);
+        if (e != hipSuccess) return fail(std::string("exchange plan: ") + hipGetErrorString(e));
+        if (rc) return 1;
+        std::vector<uint8_t> reach((size_t)c->world * g0);
+        for (int r = 0; r < c->world; ++r) std::memcpy(&reach[(size_t)r * g0], &all[(size_t)r * row], (size_t)g0);
+        const int64_t count = pi_plan_segments(c->world, g0, stride0, n, per, reach.data(), nullptr, 0);
+        std::vector<int64_t> segs((size_t)count * 4);
+        pi_plan_segments(c->world, g0, stride0, n, per, reach.data(), segs.data(), count);
+        std::vector<int64_t> recv(c->world, 0);
+        for (int64_t i = 0; i < count; ++i) recv[segs[4 * i + 1]] += segs[4 * i + 3] - segs[4 * i + 2];
+        const int64_t full = per * (c->world - 1);
+        const int64_t worst = *std::max_element(recv.begin(), recv.end());
+        plan->halo = mode == 2 || (double)worst <= 0.6 * (double)full;
+        if (plan->halo) {
+            for (int64_t i = 0; i < count; ++i) {
+                pi::ShardPlan::Seg s = {(int)segs[4 * i], (int)segs[4 * i + 1], segs[4 * i + 2], segs[4 * i + 3]};
+                if (s.src == c->rank) { plan->segs.push_back(s); plan->send_elems += s.b - s.a; }
+                else if (s.dst == c->rank) { plan->segs.push_back(s); plan->recv_elems += s.b - s.a; }
+            }
+        }
+    }
+    if (plan->halo && overlap) {
+        // sub-ranges of this shard that peers wait for (swept first), and the rest
+        std::vector<std::pair<int64_t, int64_t>> cuts;
+        for (const auto& s : plan->segs)
+            if (s.src == c->rank) cuts.push_back({s.a, s.b});
+        std::sort(cuts.begin(), cuts.end());
+        for (const auto& r : cuts) {
+            if (!plan->send_ranges.empty() && r.first <= plan->send_ranges.back().second)
+                plan->send_ranges.back().second = std::max(plan->send_ranges.back().second, r.second);
+            else
+                plan->send_ranges.push_back(r);
+        }
+        int64_t pos = plan->s_begin;
+        for (const auto& r : plan->send_ranges) {
+            if (r.first > pos) plan->interior.push_back({pos, r.first});
+            pos = std::max(pos, r.second);
+        }
+        if (pos < plan->s_end) plan->interior.push_back({pos, plan->s_end});
+        PI_HIP(hipStreamCreateWithFlags(&plan->comm_stream, hipStreamNonBlocking));
+        PI_HIP(hipEventCreateWithFlags(&plan->ev_ready, hipEventDisableTiming));
+        PI_HIP(hipEventCreateWithFlags(&plan->ev_done, hipEventDisableTiming));
+    }
+    if (!plan->halo) {
+        plan->recv_elems = per * (c->world - 1);
+        plan->send_elems = per;
+    }
+    if (info) {
+        info[0] = plan->halo ? 2 : 1;
+        info[1] = plan->recv_elems;
+        info[2] = plan->send_elems;
+        info[3] = (int64_t)plan->send_ranges.size();
+        info[4] = (int64_t)plan->interior.size();
+    }
+    pi::drop_plan(h);
+    h->plan = plan.release();
+    return 0;
+}
+
+// Make this rank's freshly written shard of `V_full` visible where the other ranks read it.
+int pi_exchange_V(pi_handle* h, float* V_full, void* stream) {
+    if (need_plan(h)) return 1;
+    pi::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->plan->halo) return h->comm->allgather(V_full, (size_t)h->plan->per * sizeof(float), st);
+    return post_exchange(h, V_full, st);
+}
+
+// n_sweeps evaluation sweeps of this rank's shard, ping-ponging between Va and Vb exactly like
+// pi_eval_sweeps, with the exchange after every sweep; d_delta (nullable) receives the residual of
+// the LAST sweep, already reduced (MAX) over all ranks.  Nothing returns to the host in between.
+int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
+                           const uint8_t* term, float gamma, int n_sweeps, float* d_delta,
+                           void* stream) {
+    if (need_plan(h)) return 1;
+    if (n_sweeps < 0) return fail("n_sweeps < 0");
+    if (!Va || !Vb || !policy || !term) return fail("null device pointer");
+    if (Va == Vb) return fail("Va and Vb must be different buffers (Jacobi sweep)");
+    if (n_sweeps == 0) return 0;
+    pi::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    pi::ShardPlan* p = h->plan;
+    const bool overlap = p->halo && p->comm_stream != nullptr;
+    for (int k = 0; k < n_sweeps; ++k) {
+        const float* src = (k & 1) ? Vb : Va;
+        float* dst = (k & 1) ? Va : Vb;
+        const bool want = k == n_sweeps - 1 && d_delta != nullptr;
+        if (overlap) {
+            for (const auto& r : p->send_ranges)
+                if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+            PI_HIP(hipEventRecord(p->ev_ready, st));
+            PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
+            if (post_exchange(h, dst, p->comm_stream)) return 1;
+            PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
+            for (const auto& r : p->interior)
+                if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+            PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
+        } else {
+            if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st)) return 1;
+            if (pi_exchange_V(h, dst, stream)) return 1;
+        }
+    }
+    if (d_delta) {
+        if (p->s_end == p->s_begin) PI_HIP(hipMemsetAsync(d_delta, 0, sizeof(float), st));
+        else if (pi::finalize(h, d_delta, nullptr, st)) return 1;
+        return h->comm->allreduce_max_f32(d_delta, st);
+    }
+    return 0;
+}
+
+// Greedy improvement of this rank's shard; d_changed (nullable) = entries changed, summed over ranks.
+int pi_improve_sweep_sharded(pi_handle* h, const float* V, int32_t* policy, const uint8_t* term,
+                             float gamma, uint32_t* d_changed, void* stream) {
+    if (need_plan(h)) return 1;
+    if (pi_improve_sweep(h, V, policy, term, h->plan->s_begin, h->plan->s_end, gamma, d_changed, stream)) return 1;
+    if (d_changed) {
+        pi::DeviceGuard guard(h->device);
+        return h->comm->allreduce_sum_u32(d_changed, (hipStream_t)stream);
+    }
+    return 0;
+}
+
+}  // extern "C"

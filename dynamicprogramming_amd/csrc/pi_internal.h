@@ -1,0 +1,96 @@
+// pi_internal.h — shared between pi_api.cpp (handles, hipRTC, launches) and pi_comm.cpp
+// (multi-GPU transports and the sharded sweep driver).  Not part of the C ABI.
+#pragma once
+
+#include "pi_mi355.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace pi {
+
+int fail(const std::string& msg);                 // records the thread-local error, returns 1
+const std::string& last_error();
+
+#define PI_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return ::pi::fail(std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+constexpr int kBlock = 256;      // PI_BLOCK of the kernel template
+constexpr int kXcds = 8;         // PI_NXCD
+constexpr int kSlots = 256;      // PI_NSLOT
+
+// Makes `device` current for the lifetime of the guard and restores the caller's device after.
+struct DeviceGuard {
+    int saved = -1;
+    bool active = false;
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        if (saved != device) active = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (active && saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
+struct Comm;   // pi_comm.cpp
+struct ShardPlan;
+
+struct GraphEntry {               // one captured batch of evaluation sweeps
+    const void *Va = nullptr, *Vb = nullptr, *policy = nullptr, *term = nullptr, *d_delta = nullptr;
+    int64_t s_begin = 0, s_end = 0;
+    float gamma = 0.0f;
+    int n_sweeps = 0;
+    hipGraphExec_t exec = nullptr;
+    uint64_t stamp = 0;
+};
+
+}  // namespace pi
+
+struct pi_handle {
+    int device = -1;
+    int D = 0;
+    int n_actions = 0;
+    int64_t n_states = 0;
+    std::vector<int32_t> shape;
+    std::vector<float> lo, span, rcp;
+    std::vector<int> fastdiv;
+    std::vector<float> tab;              // actions | bins_0 | bins_1 | ...
+    float* d_tab = nullptr;
+    unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed
+    hipModule_t module = nullptr;
+    hipFunction_t f_eval = nullptr, f_improve = nullptr, f_value = nullptr, f_finalize = nullptr,
+                  f_reach_planes = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
+                  f_probe_coords = nullptr;
+    int num_cu = 0;
+    int cpw_eval = 1, cpw_improve = 1;   // 256-state chunks a workgroup sweeps
+    int vgpr_eval = -1, vgpr_improve = -1;
+    bool cache_hit = false;
+    bool use_graphs = true;
+    std::vector<pi::GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank
+    pi::ShardPlan* plan = nullptr;       // exchange plan (owned; pi_comm.cpp)
+};
+
+namespace pi {
+
+int check_ready(const pi_handle* h);
+int check_range(const pi_handle* h, int64_t s_begin, int64_t s_end);
+// One evaluation sweep over [s_begin, s_end) WITHOUT the finalize step: the residual stays in the
+// accumulator slots (want_delta) until finalize_delta is called, so several sub-range launches of
+// one logical sweep can share it.
+int launch_eval(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const uint8_t* term,
+                int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st);
+int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
+void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
+
+}  // namespace pi

@@ -1,12 +1,13 @@
 // pi_sweep_kernels.hip — Bellman-backup sweep kernels for gfx950 (MI355X, CDNA4).
 //
 // This is a device-code TEMPLATE, never compiled on its own.  libpi_mi355.so
-// (pi_api.cpp) builds one translation unit per (grid shape, action count, env):
+// (pi_api.cpp) builds one translation unit per (grid, action count, env):
 //
-//     <generated #defines: PI_D, PI_NA, PI_GRID_INIT, PI_SPT, PI_SCHED, PI_TILE_INIT, ...>
+//     <generated #defines: PI_D, PI_NA, PI_GRID_INIT, PI_LO_INIT, PI_SPAN_INIT, PI_RCP_INIT,
+//                          PI_FASTDIV_INIT>
 //     <include/pi_math.h>  + #define sinf/cosf/fmodf -> pi_*   (deterministic math)
 //     <the user's step_dynamics C string>                       (env plugin)
-//     <this file>  +  pi_tile_kernels.hip (opt-in tile-staged family, reach probe)
+//     <this file>
 //
 // and compiles it with hipRTC (--offload-arch=gfx950 -O3 -ffp-contract=off).
 // __graft_entry__.build() runs the same assembly through `hipcc --genco` for the
@@ -18,40 +19,37 @@
 //   improvement sweep  policy_improve_kernel :244-283 / _4d :651-691 / _6d :1081-1123
 //   max|V'-V|          cp.ReductionKernel :164-172   (fused here: no second pass)
 //   policy-stable test old.copy() / all(==) :340,:354 (fused here: changed counter)
-// One thread owns one state, as in the reference; what is different is everything
-// around it: state coordinates come from per-dimension bin tables in LDS instead of
-// an (n, D) float array in HBM (16-24 B/state of traffic removed), grid shape and
-// strides are compile-time constants, the 2^D corner weights share their partial
-// products, the residual and the changed-count are reduced with wave shuffles and
-// one atomic per workgroup, and workgroups walk the state range in an XCD-aware
-// order so that each XCD's private L2 sees one contiguous slab of V.
+// One thread owns one state, as in the reference.
 //
-// Arithmetic contract (bit-exact against oracle/pi_oracle.cpp): fp32 throughout,
-// no contraction, IEEE division, the fmaf chain over corners in ascending corner
-// order from 0.0f, `reward + gamma * E` as mul then add, strict `>` argmax from
-// -1.0e30f (lowest index wins ties, NaN never wins).
+// What bounds these kernels on MI355X, and what the code does about it (DESIGN.md section 4,
+// profiles/r02): the sweeps are bound by fp32 VALU *issue*, and wave64 instructions do not all
+// cost the same — v_fma/v_mul/v_add/v_and/v_xor/v_add_u32 issue in ~2.3 cycles per SIMD,
+// everything else (compares, selects, min/max, conversions, shifts, integer multiplies, the
+// v_div_* helpers, packed and fp64 ops) in ~4.2, transcendentals in ~8.2
+// (tools/valu_issue_bench.hip).  So:
+//   * the interpolation's IEEE divisions (s - lo) / (hi - lo) have a per-dimension constant
+//     divisor: they run as a * rcp, one residual fma and one correction fma — bit-identical to
+//     the IEEE quotient for every dividend in [2^-40, 2^40], which the host PROVES per divisor
+//     by exhaustive enumeration before it enables the path (pi_api.cpp, validate_fast_division);
+//     lanes outside that range take the IEEE division; on the proven path the border clamp is the
+//     fma's free output modifier instead of a min and a max;
+//   * every address is a 32-bit byte offset from a scalar base (global_load ... v, s[..]), so
+//     there is no 64-bit vector address arithmetic;
+//   * all loads a state needs up front (mask, policy, old value) are issued before the first
+//     wait, and a workgroup sweeps several consecutive chunks, prefetching the next chunk's
+//     while it computes the current one;
+//   * the residual and the changed-count are reduced inside a wave (shuffles) and leave through
+//     one atomic per wave into one of 256 slots: no workgroup barrier after the prologue.
+//
+// Arithmetic contract (bit-exact against oracle/pi_oracle.cpp): fp32 throughout, no
+// contraction, the fmaf chain over corners in ascending corner order from 0.0f,
+// `reward + gamma * E` as mul then add, strict `>` argmax from -1.0e30f (lowest index wins
+// ties, NaN never wins).
 
 #define PI_C (1 << PI_D)
 #define PI_BLOCK 256
-// Optional occupancy targets (waves per SIMD) for the two hot kernels; 0 = let the compiler
-// decide.  Second argument of __launch_bounds__ on AMD = minimum waves per SIMD (EU).
-#ifndef PI_EVAL_MIN_WAVES
-#define PI_EVAL_MIN_WAVES 0
-#endif
-#ifndef PI_IMPROVE_MIN_WAVES
-#define PI_IMPROVE_MIN_WAVES 0
-#endif
-#if PI_EVAL_MIN_WAVES > 0
-#define PI_LB_EVAL __launch_bounds__(PI_BLOCK, PI_EVAL_MIN_WAVES)
-#else
-#define PI_LB_EVAL __launch_bounds__(PI_BLOCK)
-#endif
-#if PI_IMPROVE_MIN_WAVES > 0
-#define PI_LB_IMPROVE __launch_bounds__(PI_BLOCK, PI_IMPROVE_MIN_WAVES)
-#else
-#define PI_LB_IMPROVE __launch_bounds__(PI_BLOCK)
-#endif
 #define PI_NXCD 8
+#define PI_NSLOT 256       // accumulator slots for the residual / the changed-count
 
 // ---- compile-time grid geometry ------------------------------------------------
 struct PiGrid {
@@ -59,6 +57,7 @@ struct PiGrid {
     int stride[PI_D];
     int bins_off[PI_D];   // offset of dimension d's bin table inside the float table
     int tab_len;
+    long long n;
 };
 __host__ __device__ constexpr PiGrid pi_make_grid() {
     PiGrid r = {};
@@ -66,17 +65,26 @@ __host__ __device__ constexpr PiGrid pi_make_grid() {
     for (int d = 0; d < PI_D; ++d) r.g[d] = g[d];
     r.stride[PI_D - 1] = 1;
     for (int d = PI_D - 2; d >= 0; --d) r.stride[d] = r.stride[d + 1] * r.g[d + 1];
-    int off = 2 * PI_D + PI_NA;
+    int off = PI_NA;
     for (int d = 0; d < PI_D; ++d) { r.bins_off[d] = off; off += r.g[d]; }
     r.tab_len = off;
+    r.n = 1;
+    for (int d = 0; d < PI_D; ++d) r.n *= r.g[d];
     return r;
 }
 constexpr PiGrid PI_GRID = pi_make_grid();
-// Float table layout (device buffer `tab`, built by pi_create):
-//   [0, D) bounds_low | [D, 2D) bounds_high | [2D, 2D+NA) actions | bins_0 | bins_1 | ...
-#define PI_TAB_LO 0
-#define PI_TAB_HI PI_D
-#define PI_TAB_ACT (2 * PI_D)
+// Float table (device buffer `tab`, built by pi_create):  actions[NA] | bins_0 | bins_1 | ...
+#define PI_TAB_ACT 0
+// Interpolation constants, exact float32 values printed as hex-float literals by the host:
+// bounds_low, hi - lo (rounded once, as the reference's kernels compute it), and the correctly
+// rounded reciprocal of that span.  PI_FASTDIV[d] = 1 when the host has proven the
+// reciprocal-multiply division exact for dimension d's divisor.
+constexpr float PI_LO[PI_D] = PI_LO_INIT;
+constexpr float PI_SPAN[PI_D] = PI_SPAN_INIT;
+constexpr float PI_RCP[PI_D] = PI_RCP_INIT;
+constexpr int PI_FASTDIV[PI_D] = PI_FASTDIV_INIT;
+// V offsets as 32-bit BYTE offsets (4 n < 2^32) — otherwise 64-bit element indexing.
+constexpr bool PI_OFF32 = PI_GRID.n * 4 < (1LL << 32);
 
 // Which dimension-bit of the partial-product index a corner number selects.
 // 4D/6D: bit d of corner c <-> dimension d (:607, :1035).  2D is written out with
@@ -109,21 +117,79 @@ __device__ __forceinline__ void pi_dynamics(const float (&s)[PI_D], float a, flo
 #endif
 }
 
-// Cell of a continuous point: flat index of its lowest corner and the D fractional offsets
-// (get_barycentric_*: normalise, clamp to the border, truncate, `frac = n - i`).
-__device__ __forceinline__ void pi_locate(const float (&ns)[PI_D], const float* __restrict__ tab,
-                                          int& base, float (&fr)[PI_D]) {
-    base = 0;
+// ---- interpolation ---------------------------------------------------------------
+// (s - lo) / (hi - lo) for every dimension.  Fast path: q = a * rcp is within an ulp of the
+// quotient, r = fma(-q, span, a) is the exact residual, fma(r, rcp, q) rounds to the IEEE
+// quotient (Markstein); proven per divisor on the host for every float32 significand, so the
+// only run-time condition is that no intermediate leaves the normal range: 2^-40 <= |a| < 2^40
+// (the host requires 2^-30 <= span <= 2^30).  NaN dividends may take either path (NaN both ways).
+constexpr bool pi_any_fastdiv() {
+    for (int d = 0; d < PI_D; ++d) if (PI_FASTDIV[d]) return true;
+    return false;
+}
+constexpr bool pi_all_fastdiv() {
+    for (int d = 0; d < PI_D; ++d) if (!PI_FASTDIV[d]) return false;
+    return true;
+}
+
+// One dimension of get_barycentric_*: clamp the grid coordinate n to [0, g-1] (NaN lands on the
+// top border: fminf/fmaxf return the non-NaN operand), truncate, `frac = n - i`.
+__device__ __forceinline__ void pi_cell_1d(float n, int d, unsigned int& base, float& fr) {
+    const float top = (float)(PI_GRID.g[d] - 1);
+    n = fmaxf(0.0f, fminf(n, top));
+    const int i = min((int)n, PI_GRID.g[d] - 2);
+    fr = n - (float)i;
+    base += (unsigned int)i * (unsigned int)PI_GRID.stride[d];
+}
+
+// Cell of a continuous point: flat index of its lowest corner and the D fractional offsets.
+// n_d = (s_d - lo_d) / (hi_d - lo_d) * (g_d - 1), divide then multiply, as the reference.
+//
+// Fast path (all lanes of practical interest): the divisor is a per-dimension constant, so
+// q = a * rcp is within an ulp of the quotient, r = fma(-q, span, a) is the exact residual and
+// fma(r, rcp, q) rounds to the IEEE quotient (Markstein) — proven per divisor on the host for
+// every float32 significand; the run-time condition is only that nothing leaves the normal range:
+// 2^-40 <= |a_d| and sum |a_d| < 2^40 (the host requires 2^-30 <= span <= 2^30).  A NaN or Inf
+// coordinate fails the sum test, so the fast path never sees one and may clamp the QUOTIENT to
+// [0, 1] with the fma's free output modifier instead of clamping n with a min and a max:
+// for a finite q both give the same n (RN(q * top) is monotone in q and exact at q = 0 and 1).
+// Every other lane takes the IEEE division and the min/max clamp.
+__device__ __forceinline__ void pi_locate(const float (&ns)[PI_D], unsigned int& base,
+                                          float (&fr)[PI_D]) {
+    float a[PI_D];
 #pragma unroll
-    for (int d = 0; d < PI_D; ++d) {
-        const float lo = tab[PI_TAB_LO + d];       // wave-uniform: scalar loads
-        const float hi = tab[PI_TAB_HI + d];
-        const float top = (float)(PI_GRID.g[d] - 1);
-        float n = (ns[d] - lo) / (hi - lo) * top;
-        n = fmaxf(0.0f, fminf(n, top));            // clamp-to-border; NaN lands on `top`
-        int i = min((int)n, PI_GRID.g[d] - 2);
-        fr[d] = n - (float)i;
-        base += i * PI_GRID.stride[d];
+    for (int d = 0; d < PI_D; ++d) a[d] = ns[d] - PI_LO[d];
+    base = 0u;
+    bool fast = false;
+    if (pi_any_fastdiv()) {
+        float asum = 0.0f, amin = 1.0f;
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d)
+            if (PI_FASTDIV[d]) {
+                asum += fabsf(a[d]);
+                amin = fminf(amin, fabsf(a[d]));
+            }
+        fast = (asum < 0x1p40f) & (amin >= 0x1p-40f);
+    }
+    if (__builtin_expect(fast, 1)) {
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d) {
+            if (PI_FASTDIV[d]) {
+                const float t = a[d] * PI_RCP[d];
+                const float r = fmaf(-t, PI_SPAN[d], a[d]);
+                const float q = __builtin_amdgcn_fmed3f(fmaf(r, PI_RCP[d], t), 0.0f, 1.0f);
+                const float n = q * (float)(PI_GRID.g[d] - 1);
+                const int i = min((int)n, PI_GRID.g[d] - 2);
+                fr[d] = n - (float)i;
+                base += (unsigned int)i * (unsigned int)PI_GRID.stride[d];
+            } else {
+                pi_cell_1d(a[d] / PI_SPAN[d] * (float)(PI_GRID.g[d] - 1), d, base, fr[d]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d)
+            pi_cell_1d(a[d] / PI_SPAN[d] * (float)(PI_GRID.g[d] - 1), d, base, fr[d]);
     }
 }
 
@@ -144,17 +210,39 @@ __device__ __forceinline__ void pi_corner_weights(const float (&fr)[PI_D], float
     }
 }
 
-// Multilinear interpolation of V over the cell: all 2^D loads are issued first (corner pairs
-// along the last dimension are adjacent in memory and fuse into 8-byte loads), then the
-// fmaf chain runs in ascending corner order from 0.0f like the reference's.
-__device__ __forceinline__ float pi_interpolate(const float* __restrict__ V, int base,
+// Two adjacent floats with 4-byte alignment: one global_load_dwordx2.
+struct __attribute__((packed, aligned(4))) PiPair { float lo, hi; };
+
+// Multilinear interpolation of V over the cell.  All 2^D values are requested first — the two
+// corners along the last dimension are adjacent in memory and come as one 8-byte load — then
+// the fmaf chain runs in ascending corner order from 0.0f like the reference's.
+// Addressing: a 32-bit BYTE offset from the scalar table pointer (global_load ... v, s[..]) where
+// 4 n < 2^32; corners that differ in the slow dimensions cost one 32-bit add each, the
+// second-to-last dimension rides in the instruction's immediate offset.
+__device__ __forceinline__ float pi_interpolate(const float* __restrict__ V, unsigned int base,
                                                 const float (&fr)[PI_D]) {
+    float v[PI_C];
+    constexpr int kLast = 1 << (PI_D - 1);          // mask bit of the last dimension
+    constexpr int kNear = PI_D >= 2 ? 1 << (PI_D - 2) : 0;
+#pragma unroll
+    for (int m = 0; m < PI_C; ++m) {
+        if (m & (kLast | kNear)) continue;           // m: corner mask over the slow dimensions
+        int far = 0;
+#pragma unroll
+        for (int d = 0; d < PI_D - 2; ++d) far += ((m >> d) & 1) * PI_GRID.stride[d];
+        const char* p;
+        if (PI_OFF32) p = reinterpret_cast<const char*>(V) + (base * 4u + (unsigned int)far * 4u);
+        else p = reinterpret_cast<const char*>(V + ((unsigned long long)base + (unsigned long long)far));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const PiPair pr = *reinterpret_cast<const PiPair*>(p + (long)nb * PI_GRID.stride[PI_D - 2] * 4);
+            const int mask = m | (nb ? kNear : 0);
+            v[pi_corner_mask(mask)] = pr.lo;         // pi_corner_mask is its own inverse
+            v[pi_corner_mask(mask | kLast)] = pr.hi;
+        }
+    }
     float w[PI_C];
     pi_corner_weights(fr, w);
-    const float* __restrict__ Vb = V + base;
-    float v[PI_C];
-#pragma unroll
-    for (int c = 0; c < PI_C; ++c) v[c] = Vb[pi_corner_offset(c)];
     float e = 0.0f;
 #pragma unroll
     for (int c = 0; c < PI_C; ++c) e = fmaf(w[pi_corner_mask(c)], v[c], e);
@@ -162,22 +250,24 @@ __device__ __forceinline__ float pi_interpolate(const float* __restrict__ V, int
 }
 
 __device__ __forceinline__ float pi_backup(const float (&s)[PI_D], float a,
-                                           const float* __restrict__ V,
-                                           const float* __restrict__ tab, float gamma) {
+                                           const float* __restrict__ V, float gamma) {
     float ns[PI_D], reward;
     bool done;
     pi_dynamics(s, a, ns, &reward, &done);
     float e = 0.0f;
     if (!done) {
-        int base;
+        unsigned int base;
         float fr[PI_D];
-        pi_locate(ns, tab, base, fr);
+        pi_locate(ns, base, fr);
         e = pi_interpolate(V, base, fr);
     }
     return reward + gamma * e;
 }
 
-// Flat state index -> coordinates, through the LDS copy of the bin tables.
+// ---- state coordinates -------------------------------------------------------------
+// Flat state index -> coordinates, through the LDS copy of the bin tables (the divisions are by
+// compile-time constants: a multiply-high, a shift and a multiply-add each; on gfx950 a 32-bit
+// integer multiply issues at the same rate as a compare or a shift, tools/valu_issue_bench.hip).
 __device__ __forceinline__ void pi_state_coords(unsigned int s, const float* lds_tab,
                                                 float (&x)[PI_D]) {
     unsigned int r = s;
@@ -190,37 +280,42 @@ __device__ __forceinline__ void pi_state_coords(unsigned int s, const float* lds
     x[0] = lds_tab[PI_GRID.bins_off[0] + (int)r];
 }
 
-// Workgroup -> 256-state chunk schedule.  Workgroups are dealt round-robin over the
-// 8 XCDs (blockIdx % 8 shares an L2), so XCD x walks chunks [x*span, (x+1)*span) in
-// order: every L2 sees one contiguous slab of V.  Placement only affects speed.
-// The host launches one workgroup per chunk by default (the loops below then run once): the
-// dispatcher starts workgroups in index order, so the chunks in flight on an XCD form one
-// compact advancing window — measured 5x less traffic past L2 than a grid-stride launch with
-// 8 resident workgroups per CU.  Fewer workgroups still work (grid-stride).
-struct PiChunks {
-    long long n_chunks, span, j, step, x;
-};
-#ifndef PI_SCHED
-#define PI_SCHED 0      // 0: one contiguous slab per XCD (default); 1: plain grid-stride (tuning)
-#endif
-__device__ __forceinline__ PiChunks pi_chunks_of(long long n_chunks) {
-    PiChunks c;
-    c.n_chunks = n_chunks;
-#if PI_SCHED == 0
-    c.span = (c.n_chunks + PI_NXCD - 1) / PI_NXCD;
-    c.x = blockIdx.x % PI_NXCD;
-    c.j = blockIdx.x / PI_NXCD;
-    c.step = gridDim.x / PI_NXCD;      // host launches a multiple of 8 workgroups
-#else
-    c.span = c.n_chunks;
-    c.x = 0;
-    c.j = blockIdx.x;
-    c.step = gridDim.x;
-#endif
-    return c;
+// ---- workgroup -> chunk schedule ---------------------------------------------------
+// A workgroup sweeps `cpw` consecutive 256-state chunks (a "group").  Workgroups are dealt
+// round-robin over the 8 XCDs (blockIdx % 8 shares an L2: tools/xcc_probe.hip), so XCD x is given
+// the contiguous run of groups [x * span, (x + 1) * span): every private L2 sees one slab of V,
+// and because the dispatcher starts workgroups in index order the states in flight on an XCD
+// form one compact, advancing window (measured 5x less traffic past L2 than a grid-stride launch,
+// profiles/r01).  Placement only affects speed.  Returns false when the workgroup has no group.
+__device__ __forceinline__ bool pi_first_chunk(long long count, int cpw, long long& chunk0,
+                                               long long& n_chunks) {
+    n_chunks = (count + PI_BLOCK - 1) / PI_BLOCK;
+    const long long groups = (n_chunks + cpw - 1) / cpw;
+    const long long span = (groups + PI_NXCD - 1) / PI_NXCD;
+    const long long x = blockIdx.x % PI_NXCD, j = blockIdx.x / PI_NXCD;
+    const long long g = x * span + j;
+    chunk0 = g * cpw;
+    return j < span && g < groups;
 }
-__device__ __forceinline__ PiChunks pi_chunks(long long count) {
-    return pi_chunks_of((count + PI_BLOCK - 1) / PI_BLOCK);
+
+// Bin tables and actions -> LDS.  All loads are issued before the first store.
+__device__ __forceinline__ void pi_stage_table(const float* __restrict__ tab, float* lds_tab) {
+    constexpr int kPer = (PI_GRID.tab_len + PI_BLOCK - 1) / PI_BLOCK;
+    if (kPer <= 8) {
+        float t[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = j * PI_BLOCK + (int)threadIdx.x;
+            t[j] = tab[min(i, PI_GRID.tab_len - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = j * PI_BLOCK + (int)threadIdx.x;
+            if (i < PI_GRID.tab_len) lds_tab[i] = t[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+    }
 }
 
 __device__ __forceinline__ float pi_wave_max(float v) {
@@ -231,251 +326,116 @@ __device__ __forceinline__ float pi_wave_max(float v) {
     }
     return v;
 }
-
-// ---- transition records ------------------------------------------------------------
-// Under a FIXED policy the transition of every state (reward, cell, fractional offsets) is
-// the same in every evaluation sweep; only V changes.  The first sweep of a policy
-// evaluation can therefore record it (PI_BUILD) and the remaining sweeps — thousands of them
-// at gamma = 0.999 — replay the records instead of re-running the dynamics: the same fp32
-// operations on the same operands, hence bit-identical V, at a few loads per state instead of
-// ~450 VALU instructions.  MI355X's 288 GB make this a non-issue in size: (2 + D) * 4 B per
-// state, 0.98 GB for the 80^4 grid, 7.8 GB for 25^6.
-// Layout (struct of arrays over k = s - s_base, s_base = s_begin rounded down to 4;
-// `cap` entries per array, a multiple of 4):  reward[cap] | base[cap] | frac_0[cap] | ...
-//   base >= 0 : flat index of the cell's lowest corner
-//   base = -1 : the transition terminates (E = 0, V' = reward + gamma * 0)
-//   base = -2 : terminal grid node (V' = V)
-#ifndef PI_STREAM_NT
-#define PI_STREAM_NT 1
-#endif
-#if PI_STREAM_NT
-#define PI_STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define PI_STREAM_LOAD(p) (*(p))
-#endif
-#define PI_REC_DONE (-1)
-#define PI_REC_TERMINAL (-2)
-#ifndef PI_SPT
-#define PI_SPT 2              // states per thread in the replay kernel (1, 2 or 4)
-#endif
-
-// Residual / changed-count are accumulated into PI_NSLOT slots (one word saturates at ~90
-// atomics per microsecond on MI355X: with one counter an exact-grid improvement sweep of 80^4
-// spent 4 ms of its 7 ms in 640 k same-address atomics) and folded by pi_finalize_kernel.
-#define PI_NSLOT 256
-__device__ __forceinline__ void pi_block_max_to(float dmax, float* lds_red,
-                                                unsigned int* __restrict__ delta_bits) {
+// Residual of a wave -> one of the PI_NSLOT accumulator words (bit pattern of a float >= 0
+// orders like an unsigned int; one word saturates at ~90 atomics per microsecond on MI355X,
+// hence the slots; pi_finalize_kernel folds them).
+__device__ __forceinline__ void pi_wave_max_to(float dmax, unsigned int* __restrict__ delta_bits) {
     dmax = pi_wave_max(dmax);
-    if ((threadIdx.x & 63) == 0) lds_red[threadIdx.x >> 6] = dmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = lds_red[0];
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f)
+        atomicMax(delta_bits + ((blockIdx.x * (PI_BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)),
+                  __float_as_uint(dmax));
+}
+__device__ __forceinline__ void pi_wave_sum_to(unsigned int c, unsigned int* __restrict__ slots) {
 #pragma unroll
-        for (int w = 1; w < PI_BLOCK / 64; ++w) m = lds_red[w] > m ? lds_red[w] : m;
-        if (m > 0.0f) atomicMax(delta_bits + (blockIdx.x & (PI_NSLOT - 1)), __float_as_uint(m));
-    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c != 0u)
+        atomicAdd(slots + ((blockIdx.x * (PI_BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)), c);
+}
+
+// Per-state inputs of a sweep, requested together so that one wait covers them.  Addresses are
+// (scalar chunk base) + (32-bit lane offset): no vector 64-bit arithmetic.
+struct PiStateIn {
+    float v_old;
+    int action;
+    unsigned char term;
+};
+template <typename T>
+__device__ __forceinline__ const T* pi_lane_ptr(const T* chunk_base, unsigned int lane) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(chunk_base) +
+                                      lane * (unsigned int)sizeof(T));
+}
+__device__ __forceinline__ PiStateIn pi_load_state(const float* __restrict__ V,
+                                                   const int* __restrict__ policy,
+                                                   const unsigned char* __restrict__ term,
+                                                   long long sb, unsigned int lane) {
+    PiStateIn in;
+    // policy and mask are read exactly once per sweep: stream them (nt) so they do not displace
+    // V lines, which neighbouring states re-read, from L2 / Infinity Cache.
+    in.term = __builtin_nontemporal_load(pi_lane_ptr(term + sb, lane));
+    in.action = __builtin_nontemporal_load(pi_lane_ptr(policy + sb, lane));
+    in.v_old = *pi_lane_ptr(V + sb, lane);
+    return in;
+}
+template <typename T>
+__device__ __forceinline__ void pi_store_lane(T* chunk_base, unsigned int lane, T value) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(chunk_base) + lane * (unsigned int)sizeof(T)) = value;
 }
 
 // ---- policy evaluation sweep ---------------------------------------------------
 // Vn[s] = r(s, pi(s)) + gamma * E[V](s')   for s in [s_begin, s_end); terminal: copy.
-// delta_bits (nullable): atomic max of the bit pattern of max|Vn - V| (>= 0, so the
-// unsigned order is the float order); the host zeroes it before the launch.
-// BUILD: additionally write the transition records (rec, cap) described above.
-template <bool BUILD>
-__device__ __forceinline__ void pi_eval_body(const float* __restrict__ V, float* __restrict__ Vn,
-                                             const int* __restrict__ policy,
-                                             const unsigned char* __restrict__ term,
-                                             const float* __restrict__ tab, long long s_begin,
-                                             long long s_end, float gamma,
-                                             unsigned int* __restrict__ delta_bits,
-                                             float* __restrict__ rec, long long cap) {
+// delta_bits (nullable): slots receiving the atomic max of the bit pattern of |Vn - V|.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
+                     const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                     const float* __restrict__ tab, long long s_begin, long long s_end,
+                     float gamma, unsigned int* __restrict__ delta_bits, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
-    __shared__ float lds_red[PI_BLOCK / 64];
-    for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+
+    const unsigned int tid = threadIdx.x;
+    long long sb = s_begin + chunk0 * PI_BLOCK;                     // first state of the chunk
+    // lanes past s_end (tail of the last chunk) shadow the last valid state and store nothing
+    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
+    pi_stage_table(tab, lds_tab);
     __syncthreads();
 
-    const long long s_base = s_begin & ~3LL;
-    const PiChunks ck = pi_chunks(s_end - s_begin);
     float dmax = 0.0f;
-    for (long long cl = ck.j; cl < ck.span; cl += ck.step) {
-        const long long chunk = ck.x * ck.span + cl;
-        if (chunk >= ck.n_chunks) break;
-        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
-        if (s >= s_end) continue;
-        const float v_old = V[s];
-        float nv = v_old;
-        int base = PI_REC_TERMINAL;
-        float reward = 0.0f, fr[PI_D];
-#pragma unroll
-        for (int d = 0; d < PI_D; ++d) fr[d] = 0.0f;
-        // policy and mask are read exactly once per sweep: stream them (nt) so they do not
-        // displace V lines, which every neighbouring state re-reads, from L2 / Infinity Cache.
-        if (!PI_STREAM_LOAD(&term[s])) {
-            float x[PI_D], ns[PI_D];
-            pi_state_coords((unsigned int)s, lds_tab, x);
-            const float a = lds_tab[PI_TAB_ACT + PI_STREAM_LOAD(&policy[s])];
+    for (int k = 0; k < n_here; ++k) {
+        const PiStateIn cur = nxt;
+        const long long sb_c = sb;
+        const unsigned int lane_c = lane;
+        if (k + 1 < n_here) {                                        // prefetch the next chunk's inputs
+            sb += PI_BLOCK;
+            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+            nxt = pi_load_state(V, policy, term, sb, lane);
+        }
+        float nv = cur.v_old;
+        if (!cur.term) {
+            float x[PI_D], ns[PI_D], reward;
+            pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
+            const float a = lds_tab[PI_TAB_ACT + cur.action];
             bool done;
             pi_dynamics(x, a, ns, &reward, &done);
             float e = 0.0f;
-            base = PI_REC_DONE;
             if (!done) {
-                pi_locate(ns, tab, base, fr);
+                unsigned int base;
+                float fr[PI_D];
+                pi_locate(ns, base, fr);
                 e = pi_interpolate(V, base, fr);
             }
             nv = reward + gamma * e;
         }
-        Vn[s] = nv;
-        if (BUILD) {
-            const long long k = s - s_base;
-            rec[k] = reward;
-            reinterpret_cast<int*>(rec)[cap + k] = base;
-#pragma unroll
-            for (int d = 0; d < PI_D; ++d) rec[(2 + d) * cap + k] = fr[d];
-        }
-        const float dlt = fabsf(nv - v_old);
-        dmax = dlt > dmax ? dlt : dmax;
-    }
-    if (delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
-}
-
-extern "C" __global__ void PI_LB_EVAL
-pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
-                     const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                     const float* __restrict__ tab, long long s_begin, long long s_end,
-                     float gamma, unsigned int* __restrict__ delta_bits) {
-    pi_eval_body<false>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, nullptr, 0);
-}
-
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
-pi_eval_build_kernel(const float* __restrict__ V, float* __restrict__ Vn,
-                     const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                     const float* __restrict__ tab, long long s_begin, long long s_end,
-                     float gamma, unsigned int* __restrict__ delta_bits,
-                     float* __restrict__ rec, long long cap) {
-    pi_eval_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, rec, cap);
-}
-
-// ---- evaluation sweep from the transition records (the steady-state hot loop) --------
-// HBM-bound: per state (2 + D) * 4 B of records in, 4 B of V' out, the 2^D corner reads of V
-// served by L2 / Infinity Cache.  Each thread owns PI_SPT consecutive states so the record
-// loads and the V' store are 8- or 16-byte accesses; chunks are aligned to s_base so those
-// vectors are naturally aligned whatever the shard boundaries are.
-template <int N> struct PiVec {
-    typedef float f __attribute__((ext_vector_type(N)));
-    typedef int i __attribute__((ext_vector_type(N)));
-};
-template <> struct PiVec<1> { typedef float f; typedef int i; };
-
-#ifndef PI_REPLAY_NT
-#define PI_REPLAY_NT 1        // records are read once per sweep: stream them past L2 / MALL
-#endif
-#ifndef PI_REPLAY_PREFETCH
-#define PI_REPLAY_PREFETCH 1  // fetch the next chunk's records while gathering this chunk's V
-#endif
-
-template <typename T>
-__device__ __forceinline__ T pi_stream_load(const T* p) {
-#if PI_REPLAY_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-
-struct PiRecords {
-    typename PiVec<PI_SPT>::f r, f[PI_D];
-    typename PiVec<PI_SPT>::i b;
-};
-__device__ __forceinline__ void pi_load_records(PiRecords& q, const float* __restrict__ rec,
-                                                long long cap, long long k0) {
-    typedef PiVec<PI_SPT>::f vf;
-    typedef PiVec<PI_SPT>::i vi;
-    q.r = pi_stream_load(reinterpret_cast<const vf*>(rec + k0));
-    q.b = pi_stream_load(reinterpret_cast<const vi*>(reinterpret_cast<const int*>(rec) + cap + k0));
-#pragma unroll
-    for (int d = 0; d < PI_D; ++d)
-        q.f[d] = pi_stream_load(reinterpret_cast<const vf*>(rec + (2 + d) * cap + k0));
-}
-#if PI_SPT == 1
-#define PI_LANE(v, j) (v)
-#else
-#define PI_LANE(v, j) ((v)[j])
-#endif
-
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
-pi_eval_replay_kernel(const float* __restrict__ V, float* __restrict__ Vn,
-                      const float* __restrict__ rec, long long cap, long long s_begin,
-                      long long s_end, float gamma, unsigned int* __restrict__ delta_bits) {
-    typedef PiVec<PI_SPT>::f vf;
-    __shared__ float lds_red[PI_BLOCK / 64];
-    const long long s_base = s_begin & ~3LL;
-    const long long count = s_end - s_base;
-    const PiChunks ck = pi_chunks_of((count + PI_BLOCK * PI_SPT - 1) / (PI_BLOCK * PI_SPT));
-    float dmax = 0.0f;
-
-    // The chunk list of this workgroup is known up front, so the loop is software-pipelined:
-    // the records of chunk t+1 are requested before chunk t's dependent V gathers are issued.
-    long long cl = ck.j;
-    long long chunk = ck.x * ck.span + cl;
-    bool live = cl < ck.span && chunk < ck.n_chunks;
-    PiRecords cur, nxt;
-    if (live) pi_load_records(cur, rec, cap, (chunk * PI_BLOCK + threadIdx.x) * PI_SPT);
-    while (live) {
-        const long long k0 = (chunk * PI_BLOCK + threadIdx.x) * PI_SPT;
-        const long long s0 = s_base + k0;
-        const long long cl_n = cl + ck.step;
-        const long long chunk_n = ck.x * ck.span + cl_n;
-        const bool live_n = cl_n < ck.span && chunk_n < ck.n_chunks;
-#if PI_REPLAY_PREFETCH
-        if (live_n) pi_load_records(nxt, rec, cap, (chunk_n * PI_BLOCK + threadIdx.x) * PI_SPT);
-#endif
-        // Straight-line body: lanes outside [s_begin, s_end) and records without a cell
-        // (terminal node / terminating transition) gather from cell 0 and discard the result,
-        // so every load of the chunk is in flight before the first fmaf.
-        const bool full = (s0 >= s_begin) && (s0 + PI_SPT <= s_end);
-        vf out;
-        float old[PI_SPT];
-        bool ok[PI_SPT];
-#pragma unroll
-        for (int j = 0; j < PI_SPT; ++j) {
-            ok[j] = full || (s0 + j >= s_begin && s0 + j < s_end);
-            old[j] = V[ok[j] ? s0 + j : s_begin];
-        }
-#pragma unroll
-        for (int j = 0; j < PI_SPT; ++j) {
-            const int b = PI_LANE(cur.b, j);
-            float fr[PI_D];
-#pragma unroll
-            for (int d = 0; d < PI_D; ++d) fr[d] = PI_LANE(cur.f[d], j);
-            const float e = pi_interpolate(V, (ok[j] && b >= 0) ? b : 0, fr);
-            float nv = PI_LANE(cur.r, j) + gamma * (b >= 0 ? e : 0.0f);
-            nv = (b == PI_REC_TERMINAL) ? old[j] : nv;
-            const float dlt = ok[j] ? fabsf(nv - old[j]) : 0.0f;
+        if (tid == lane_c) {
+            pi_store_lane(Vn + sb_c, lane_c, nv);
+            const float dlt = fabsf(nv - cur.v_old);
             dmax = dlt > dmax ? dlt : dmax;
-            PI_LANE(out, j) = nv;
         }
-        if (full) *reinterpret_cast<vf*>(Vn + s0) = out;
-        else {
-#pragma unroll
-            for (int j = 0; j < PI_SPT; ++j) if (ok[j]) Vn[s0 + j] = PI_LANE(out, j);
-        }
-#if PI_REPLAY_PREFETCH
-        cur = nxt;
-#else
-        if (live_n) pi_load_records(cur, rec, cap, (chunk_n * PI_BLOCK + threadIdx.x) * PI_SPT);
-#endif
-        cl = cl_n;
-        chunk = chunk_n;
-        live = live_n;
     }
-    if (delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
+    if (delta_bits != nullptr) pi_wave_max_to(dmax, delta_bits);
 }
 
 // ---- greedy policy improvement sweep -------------------------------------------
 // policy[s] = argmax_a [ r(s,a) + gamma * E[V](s'_a) ], first maximum wins; terminal
-// states keep their entry.  changed (nullable): number of entries that changed.
+// states keep their entry.  changed (nullable): slots counting the entries that changed.
 // WRITE_V (value-iteration sweep, the fused form the reference's README sketches at :790-799
 // but does not implement): also Vn[s] = max_a Q(s,a) (terminal: copy) and the residual.
+// The argmax is a serial loop per lane on purpose: everything in step_dynamics that does not
+// depend on the action (in the double pendulum: all seven sin/cos and both angle wraps) is
+// hoisted out of it by the compiler; spreading the actions over lanes would redo that work
+// n_actions times.  The action values come from LDS.
 template <bool WRITE_V>
 __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, float* __restrict__ Vn,
                                                 int* __restrict__ policy,
@@ -483,65 +443,72 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
                                                 const float* __restrict__ tab, long long s_begin,
                                                 long long s_end, float gamma,
                                                 unsigned int* __restrict__ delta_bits,
-                                                unsigned int* __restrict__ changed) {
+                                                unsigned int* __restrict__ changed, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
-    __shared__ float lds_red[PI_BLOCK / 64];
-    for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+
+    const unsigned int tid = threadIdx.x;
+    long long sb = s_begin + chunk0 * PI_BLOCK;
+    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
+    pi_stage_table(tab, lds_tab);
     __syncthreads();
 
-    const PiChunks ck = pi_chunks(s_end - s_begin);
     unsigned int n_changed = 0;
     float dmax = 0.0f;
-    for (long long cl = ck.j; cl < ck.span; cl += ck.step) {
-        const long long chunk = ck.x * ck.span + cl;
-        if (chunk >= ck.n_chunks) break;
-        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
-        if (s >= s_end) continue;
-        if (term[s]) {
-            if (WRITE_V) Vn[s] = V[s];
-            continue;
+    for (int k = 0; k < n_here; ++k) {
+        const PiStateIn cur = nxt;
+        const long long sb_c = sb;
+        const unsigned int lane_c = lane;
+        if (k + 1 < n_here) {
+            sb += PI_BLOCK;
+            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+            nxt = pi_load_state(V, policy, term, sb, lane);
         }
-        float x[PI_D];
-        pi_state_coords((unsigned int)s, lds_tab, x);
-        float best_q = -1.0e30f;
-        int best = 0;
-        for (int a = 0; a < PI_NA; ++a) {
-            const float q = pi_backup(x, tab[PI_TAB_ACT + a], V, tab, gamma);
-            if (q > best_q) { best_q = q; best = a; }
-        }
-        const int old = policy[s];
-        policy[s] = best;
-        n_changed += (old != best) ? 1u : 0u;
-        if (WRITE_V) {
-            Vn[s] = best_q;
-            const float dlt = fabsf(best_q - V[s]);
-            dmax = dlt > dmax ? dlt : dmax;
+        const bool live = tid == lane_c;
+        if (!cur.term) {
+            float x[PI_D];
+            pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
+            float best_q = -1.0e30f;
+            int best = 0;
+            for (int a = 0; a < PI_NA; ++a) {
+                const float q = pi_backup(x, lds_tab[PI_TAB_ACT + a], V, gamma);
+                if (q > best_q) { best_q = q; best = a; }
+            }
+            if (live) {
+                pi_store_lane(policy + sb_c, lane_c, best);
+                n_changed += (cur.action != best) ? 1u : 0u;
+                if (WRITE_V) {
+                    pi_store_lane(Vn + sb_c, lane_c, best_q);
+                    const float dlt = fabsf(best_q - cur.v_old);
+                    dmax = dlt > dmax ? dlt : dmax;
+                }
+            }
+        } else if (WRITE_V && live) {
+            pi_store_lane(Vn + sb_c, lane_c, cur.v_old);
         }
     }
-    if (changed != nullptr) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n_changed += __shfl_xor(n_changed, o, 64);
-        if ((threadIdx.x & 63) == 0 && n_changed != 0u)
-            atomicAdd(changed + ((blockIdx.x * (PI_BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)),
-                      n_changed);
-    }
-    if (WRITE_V && delta_bits != nullptr) pi_block_max_to(dmax, lds_red, delta_bits);
+    if (changed != nullptr) pi_wave_sum_to(n_changed, changed);
+    if (WRITE_V && delta_bits != nullptr) pi_wave_max_to(dmax, delta_bits);
 }
 
-extern "C" __global__ void PI_LB_IMPROVE
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
 pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
                         const unsigned char* __restrict__ term, const float* __restrict__ tab,
                         long long s_begin, long long s_end, float gamma,
-                        unsigned int* __restrict__ changed) {
-    pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed);
+                        unsigned int* __restrict__ changed, int cpw) {
+    pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed, cpw);
 }
 
-extern "C" __global__ void PI_LB_IMPROVE
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
 pi_value_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn, int* __restrict__ policy,
                       const unsigned char* __restrict__ term, const float* __restrict__ tab,
                       long long s_begin, long long s_end, float gamma,
-                      unsigned int* __restrict__ delta_bits, unsigned int* __restrict__ changed) {
-    pi_improve_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, changed);
+                      unsigned int* __restrict__ delta_bits, unsigned int* __restrict__ changed,
+                      int cpw) {
+    pi_improve_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, changed, cpw);
 }
 
 // Fold the PI_NSLOT accumulator slots into the caller's scalars and clear them for the next
@@ -567,38 +534,48 @@ pi_finalize_kernel(unsigned int* __restrict__ delta_slots, float* __restrict__ d
     }
 }
 
-// ---- which dim-0 planes of V can the states of a range read? -----------------------------
-// For every state in [s_begin, s_end) and EVERY action: the plane (dimension-0 index) of the
-// successor's cell and the one above it are marked in a bitmap of g_0 bits.  Policy-independent,
-// so it is computed once; the multi-GPU host uses it to exchange only the planes a rank's
-// shard can reach (halo exchange) instead of all-gathering the whole V after every sweep.
-#define PI_PLANE_WORDS ((PI_GRID.g[0] + 31) / 32)
+// ---- which planes of V can the states of a range read? ---------------------------------
+// For every state in [s_begin, s_end) and EVERY action: along dimension PI_REACH_DIM (a kernel
+// argument `dim`), the index of the successor's cell and the one above it are marked in a bitmap
+// of g[dim] bits.  Policy-independent, so it is computed once; the multi-GPU host uses it to
+// exchange only the slabs a rank's shard can reach (halo exchange) instead of all-gathering the
+// whole V after every sweep, and to pick the dimension with the narrowest reach.
+constexpr int pi_max_extent() {
+    int m = 0;
+    for (int d = 0; d < PI_D; ++d) m = PI_GRID.g[d] > m ? PI_GRID.g[d] : m;
+    return m;
+}
+#define PI_PLANE_WORDS ((pi_max_extent() + 31) / 32)
 extern "C" __global__ void __launch_bounds__(PI_BLOCK)
 pi_reach_planes_kernel(const unsigned char* __restrict__ term, const float* __restrict__ tab,
-                       long long s_begin, long long s_end, unsigned int* __restrict__ bitmap) {
+                       long long s_begin, long long s_end, unsigned int* __restrict__ bitmap,
+                       int dim, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     __shared__ unsigned int lds_bits[PI_PLANE_WORDS];
-    for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const long long chunk_end = min(chunk0 + cpw, n_chunks);
+    pi_stage_table(tab, lds_tab);
     for (int i = threadIdx.x; i < PI_PLANE_WORDS; i += PI_BLOCK) lds_bits[i] = 0u;
     __syncthreads();
-    const PiChunks ck = pi_chunks(s_end - s_begin);
-    for (long long cl = ck.j; cl < ck.span; cl += ck.step) {
-        const long long chunk = ck.x * ck.span + cl;
-        if (chunk >= ck.n_chunks) break;
+    unsigned int stride_dim = 1u, g_dim = 1u;
+#pragma unroll
+    for (int d = 0; d < PI_D; ++d)
+        if (d == dim) { stride_dim = (unsigned int)PI_GRID.stride[d]; g_dim = (unsigned int)PI_GRID.g[d]; }
+    for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
         const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
-        if (s >= s_end) continue;
-        if (term[s]) continue;
+        if (s >= s_end || term[s]) continue;
         float x[PI_D];
         pi_state_coords((unsigned int)s, lds_tab, x);
         int last = -1;
         for (int a = 0; a < PI_NA; ++a) {
             float ns[PI_D], reward, fr[PI_D];
             bool done;
-            pi_dynamics(x, tab[PI_TAB_ACT + a], ns, &reward, &done);
+            pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
             if (done) continue;
-            int base;
-            pi_locate(ns, tab, base, fr);
-            const int p = base / PI_GRID.stride[0];
+            unsigned int base;
+            pi_locate(ns, base, fr);
+            const int p = (int)((base / stride_dim) % g_dim);
             if (p != last) {
                 atomicOr(&lds_bits[p >> 5], 1u << (p & 31));
                 atomicOr(&lds_bits[(p + 1) >> 5], 1u << ((p + 1) & 31));
@@ -632,19 +609,40 @@ pi_probe_step_kernel(const float* __restrict__ states, const float* __restrict__
 }
 
 extern "C" __global__ void __launch_bounds__(PI_BLOCK)
-pi_probe_interp_kernel(const float* __restrict__ pts, const float* __restrict__ tab,
-                       int* __restrict__ idxs, float* __restrict__ wgts, long long m) {
+pi_probe_interp_kernel(const float* __restrict__ pts, int* __restrict__ idxs,
+                       float* __restrict__ wgts, long long m) {
     const long long k = (long long)blockIdx.x * PI_BLOCK + threadIdx.x;
     if (k >= m) return;
     float p[PI_D], fr[PI_D], w[PI_C];
 #pragma unroll
     for (int d = 0; d < PI_D; ++d) p[d] = pts[k * PI_D + d];
-    int base;
-    pi_locate(p, tab, base, fr);
+    unsigned int base;
+    pi_locate(p, base, fr);
     pi_corner_weights(fr, w);
 #pragma unroll
     for (int c = 0; c < PI_C; ++c) {
-        idxs[k * PI_C + c] = base + pi_corner_offset(c);
+        idxs[k * PI_C + c] = (int)base + pi_corner_offset(c);
         wgts[k * PI_C + c] = w[pi_corner_mask(c)];
+    }
+}
+
+// State coordinates of arbitrary flat indices (test probe for pi_state_coords and the chunk walk):
+// out[(s - s_begin) * D + d] for s in [s_begin, s_end), walked exactly like the sweeps walk it.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_probe_coords_kernel(const float* __restrict__ tab, long long s_begin, long long s_end,
+                       float* __restrict__ out, int cpw) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const long long chunk_end = min(chunk0 + cpw, n_chunks);
+    pi_stage_table(tab, lds_tab);
+    __syncthreads();
+    for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
+        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
+        if (s >= s_end) continue;
+        float x[PI_D];
+        pi_state_coords((unsigned int)s, lds_tab, x);
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d) out[(s - s_begin) * PI_D + d] = x[d];
     }
 }

@@ -13,9 +13,9 @@ Underneath nothing is shared with the reference: the grid is described by D bin 
 V / policy / mask live in torch-ROCm tensors (device memory only), and every sweep is one
 call through the ctypes C ABI of libpi_mi355.so (include/pi_mi355.h), whose hipRTC-built
 gfx950 kernels fuse the backup, the residual reduction and the policy-change count.
-With more than one rank (``torch.distributed`` initialised, one process per GPU) the flat
-state range is split into contiguous shards; each rank sweeps its shard and the V shards
-are all-gathered (RCCL over xGMI) after every evaluation sweep.
+With more than one rank (one process per GPU) the flat state range is split into contiguous
+shards; each rank sweeps its shard and the new values travel between ranks inside the library
+(RCCL over xGMI: halo exchange of the reachable planes, or an all-gather) — see transport.py.
 
 There is no CPU or eager fallback: constructing a solver without the native library and
 a GPU raises ``RuntimeError`` exactly where the reference raises for a missing CuPy (:71-75).
@@ -64,11 +64,6 @@ class CudaPIConfig:
     max_eval_iter: int = 10_000   # sweeps per policy evaluation, at most
     max_pi_iter: int = 50         # outer evaluate/improve iterations, at most
     log_interval: int = 100       # log the residual every N sweeps (at check points)
-    # MI355X extension (results are bit-identical either way): record each state's transition
-    # on the first sweep of a policy evaluation and replay it on the following sweeps.  Off by
-    # default: on MI355X the sweeps are bound by the scattered V gather, not by the dynamics
-    # arithmetic, so replaying is only worth ~15 % on 4-D grids and loses on 6-D.
-    cache_transitions: bool = False
 
 
 class HipSweepBackend:
@@ -92,41 +87,16 @@ class HipSweepBackend:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def enable_transition_cache(self, s_begin: int, s_end: int) -> bool:
-        """Reserve the record workspace for one state range ((2 + D) * 4 B per state)."""
-        need = self.engine.transition_cache_bytes(s_begin, s_end)
-        if need == 0:
-            return False
-        try:
-            self._cache = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
-        except RuntimeError as exc:          # out of HBM: keep recomputing the dynamics
-            logger.warning(f"transition cache disabled ({need / 2**30:.1f} GiB not available): {exc}")
-            self._cache = None
-        return self._cache is not None
+    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
+        self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
+                                s_begin, s_end, gamma, n_sweeps,
+                                0 if d_delta is None else d_delta.data_ptr(), self._stream())
 
-    def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta,
-                    rebuild=True):
-        delta_ptr = 0 if d_delta is None else d_delta.data_ptr()
-        if getattr(self, "_cache", None) is not None:
-            self.engine.eval_sweeps_cached(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(),
-                                           term.data_ptr(), s_begin, s_end, gamma, n_sweeps, rebuild,
-                                           self._cache.data_ptr(), self._cache.numel(), delta_ptr,
-                                           self._stream())
-        else:
-            self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
-                                    s_begin, s_end, gamma, n_sweeps, delta_ptr, self._stream())
-
-    def autotune(self, V, Vscratch, policy, term, s_begin, s_end, gamma) -> int:
-        """Time the evaluation sweep at several workgroups-per-CU settings on this V / policy
-        and keep the fastest (blocks; Vscratch is overwritten)."""
-        return self.engine.autotune_eval(V.data_ptr(), Vscratch.data_ptr(), policy.data_ptr(),
-                                         term.data_ptr(), s_begin, s_end, gamma, self._stream())
-
-    def reach_planes(self, term, s_begin, s_end, n_planes):
-        """bool[n_planes]: dimension-0 planes of V the states of the range can read (any action)."""
+    def reach_planes(self, term, s_begin, s_end, n_planes, dim=0):
+        """bool[n_planes]: planes of V along `dim` the states of the range can read (any action)."""
         words = (n_planes + 31) // 32
         bitmap = self.torch.zeros(words, dtype=self.torch.int32, device=self.device)
-        self.engine.reach_planes(term.data_ptr(), s_begin, s_end, bitmap.data_ptr(), self._stream())
+        self.engine.reach_planes(term.data_ptr(), s_begin, s_end, bitmap.data_ptr(), self._stream(), dim=dim)
         bits = bitmap.cpu().numpy().view(np.uint32)
         return ((bits[np.arange(n_planes) >> 5] >> (np.arange(n_planes) & 31).astype(np.uint32)) & 1).astype(bool)
 
@@ -141,7 +111,6 @@ class HipSweepBackend:
                                 0 if d_changed is None else d_changed.data_ptr(), self._stream())
 
     def close(self):
-        self._cache = None
         self.engine.close()
 
 
@@ -159,7 +128,7 @@ class _CudaPolicyIterationBase(abc.ABC):
     _D: int = 0
 
     def __init__(self, bins_space: dict, action_space, config: CudaPIConfig | None = None, *,
-                 device=None, process_group=None, backend_factory=None) -> None:
+                 device=None, process_group=None, backend_factory=None, transport=None) -> None:
         """
         bins_space   : dict with exactly D keys -> 1-D arrays of grid points (insertion order
                        = dimension order), e.g. {"theta": linspace(-pi, pi, 200), ...}
@@ -167,6 +136,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         config       : CudaPIConfig
         device       : torch device of this rank (default: current CUDA device)
         process_group: torch.distributed group to shard over (default: WORLD if initialised)
+        transport    : multi-rank transport (transport.py); default: the library's RCCL transport,
+                       bootstrapped over `process_group`, when torch.distributed is initialised
         backend_factory : sweep-backend constructor; tests inject a CPU checker here, the
                        product default is the HIP backend and is never replaced silently.
         """
@@ -189,6 +160,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         self._device_arg = device
         self._process_group = process_group
         self._backend_factory = backend_factory
+        self._transport_arg = transport
         self.stats = {"eval_sweeps": 0, "improve_sweeps": 0, "pi_iterations": 0,
                       "sweeps_per_iter": [], "eval_seconds": 0.0, "improve_seconds": 0.0}
 
@@ -253,9 +225,6 @@ class _CudaPolicyIterationBase(abc.ABC):
                                 device=self._device_arg)
         dev = self._backend.device
         self._init_sharding()
-        self._records_stale = True
-        if getattr(self.config, "cache_transitions", False) and hasattr(self._backend, "enable_transition_cache"):
-            self._backend.enable_transition_cache(self._s_begin, self._s_end)
 
         n, n_pad = self.n_states, self._n_pad
         self.d_policy = torch.zeros(n_pad, dtype=torch.int32, device=dev)
@@ -276,7 +245,12 @@ class _CudaPolicyIterationBase(abc.ABC):
             self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
             logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
         self.d_new_value_function.copy_(self.d_value_function)
-        self._plan_exchange()
+        if self._comm is not None:
+            self._comm.plan(self)
+            if self._comm.halo_elems >= 0:
+                logger.info(f"halo exchange: rank {self._rank} receives "
+                            f"{self._comm.halo_elems * 4 / 2**20:.1f} MiB per sweep instead of "
+                            f"{(self._n_pad - self._shard_len) * 4 / 2**20:.1f} MiB")
         logger.success("Kernels compiled. Device memory allocated.")
 
     def _seed_values(self, mask: np.ndarray, value: float) -> None:
@@ -290,235 +264,50 @@ class _CudaPolicyIterationBase(abc.ABC):
 
     # ── sharding over ranks ─────────────────────────────────────────────────────────
     def _init_sharding(self) -> None:
-        import torch.distributed as dist
-        group = self._process_group
-        if dist.is_available() and dist.is_initialized():
-            self._world = dist.get_world_size(group)
-            self._rank = dist.get_rank(group)
-        else:
-            self._world, self._rank = 1, 0
-        n = self.n_states
-        per = -(-n // self._world)              # ceil: equal shards, the tail is padding
-        self._shard_len = per
-        self._n_pad = per * self._world
-        self._s_begin = min(self._rank * per, n)
-        self._s_end = min(self._s_begin + per, n)
-        if self._world > 1:
+        """Pick the transport (None on a single rank) and this rank's contiguous state shard."""
+        from . import transport as T
+        comm = self._transport_arg
+        if comm is None:
+            try:
+                import torch.distributed as dist
+                active = dist.is_available() and dist.is_initialized()
+            except Exception:  # noqa: BLE001
+                active = False
+            if active and dist.get_world_size(self._process_group) > 1:
+                if isinstance(self._backend, HipSweepBackend):
+                    comm = T.NativeTransport.from_torch_distributed(self._process_group)
+                else:                                   # injected CPU checker (tests): test transport
+                    comm = T.TorchDistTransport(self._process_group)
+        self._comm = comm
+        self._world, self._rank = (comm.world, comm.rank) if comm is not None else (1, 0)
+        self._shard_len, self._s_begin, self._s_end = T.shard_bounds(self.n_states, self._rank, self._world)
+        self._n_pad = self._shard_len * self._world
+        if comm is not None:
+            comm.attach(self)
             logger.info(f"rank {self._rank}/{self._world}: states [{self._s_begin:,}, {self._s_end:,})")
-
-    def _all_gather_shards(self, full) -> None:
-        """Every rank contributes full[rank*per:(rank+1)*per]; afterwards all ranks hold all."""
-        import torch.distributed as dist
-        per = self._shard_len
-        mine = full[self._rank * per:(self._rank + 1) * per]
-        if full.device.type != "cuda":
-            mine = mine.clone()                 # gloo: no aliasing between input and output
-        dist.all_gather_into_tensor(full, mine, group=self._process_group)
-
-    def _plan_exchange(self) -> None:
-        """How V' travels between ranks after an evaluation sweep.  A state's successor lies a
-        few cells away, so a rank's shard only ever reads a band of dimension-0 planes around
-        itself (plus the opposite end where an angle wraps).  Every rank measures that band once
-        (all actions, `pi_reach_planes`), the bitmaps are all-gathered, and from then on each rank
-        sends exactly the plane runs its peers can reach (point-to-point over RCCL/xGMI) instead
-        of all-gathering the whole V.  Falls back to the all-gather when the bands cover most of
-        the grid anyway.  `PI_MI355_EXCHANGE=allgather|halo` forces a mode."""
-        import os
-        self._segments = None
-        self._send_ranges = self._interior_ranges = None
-        if self._world == 1:
-            return
-        import torch
-        import torch.distributed as dist
-        mode = os.environ.get("PI_MI355_EXCHANGE", "auto")
-        if mode == "allgather" or not hasattr(self._backend, "reach_planes"):
-            return
-        g0 = int(self.grid_shape[0])
-        n, per = self.n_states, self._shard_len
-        stride0 = n // g0
-        mine = np.zeros(g0, dtype=bool)
-        if self._s_end > self._s_begin:
-            mine = self._backend.reach_planes(self.d_terminal_mask, self._s_begin, self._s_end, g0)
-        dev = self.d_value_function.device
-        allbits = torch.zeros(self._world * g0, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allbits, torch.from_numpy(mine.astype(np.uint8)).to(dev),
-                                    group=self._process_group)
-        allbits = allbits.cpu().numpy().astype(bool).reshape(self._world, g0)
-        segments = []
-        for dst in range(self._world):
-            need = allbits[dst]
-            p = 0
-            while p < g0:
-                if not need[p]:
-                    p += 1
-                    continue
-                q = p
-                while q < g0 and need[q]:
-                    q += 1
-                lo, hi = p * stride0, min(q * stride0, n)
-                for src in range(self._world):
-                    a, b = max(lo, src * per), min(hi, min((src + 1) * per, n))
-                    if src != dst and a < b:
-                        segments.append((src, dst, a, b))
-                p = q
-        recv = [sum(b - a for (_, d, a, b) in segments if d == r) for r in range(self._world)]
-        full = self._n_pad - per
-        if mode != "halo" and max(recv) > 0.6 * full:
-            logger.info(f"halo exchange would move {max(recv) / max(full, 1):.0%} of an all-gather: "
-                        "keeping the all-gather")
-            return
-        self._segments = segments
-        self._peer = [dist.get_global_rank(self._process_group, r) if self._process_group is not None
-                      else r for r in range(self._world)]
-        # Self-test on the real transport before trusting it: every rank writes "flat index" into
-        # its own shard of the scratch buffer, exchanges, and checks each plane it may read.
-        scratch = self.d_new_value_function
-        scratch.fill_(-1.0)
-        if self._s_end > self._s_begin:
-            scratch[self._s_begin:self._s_end] = torch.arange(
-                self._s_begin, self._s_end, dtype=torch.float32, device=dev)
-        self._exchange_shards(scratch)
-        bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        for p in np.flatnonzero(mine):
-            a, b = int(p) * stride0, min((int(p) + 1) * stride0, n)
-            want = torch.arange(a, b, dtype=torch.float32, device=dev)
-            bad += (scratch[a:b] != want).any().to(torch.int32)
-        self._all_reduce_scalar(bad, "SUM")
-        scratch.copy_(self.d_value_function)
-        if int(bad.item()) != 0:
-            logger.warning("halo exchange self-test failed; falling back to the all-gather")
-            self._segments = None
-            return
-        # Sub-ranges of this rank's shard: what peers wait for (swept first, then sent while the
-        # rest is swept).  Disabled with the transition cache (its records are per range).
-        self._send_ranges = self._interior_ranges = None
-        if getattr(self._backend, "_cache", None) is None and os.environ.get("PI_MI355_OVERLAP", "1") != "0":
-            cuts = sorted({(a, b) for (src, _, a, b) in segments if src == self._rank})
-            merged = []
-            for a, b in cuts:
-                if merged and a <= merged[-1][1]:
-                    merged[-1][1] = max(merged[-1][1], b)
-                else:
-                    merged.append([a, b])
-            interior, pos = [], self._s_begin
-            for a, b in merged:
-                if a > pos:
-                    interior.append((pos, a))
-                pos = max(pos, b)
-            if pos < self._s_end:
-                interior.append((pos, self._s_end))
-            self._send_ranges = [tuple(m) for m in merged]
-            self._interior_ranges = interior
-            self._d_delta_parts = torch.zeros(len(merged) + len(interior) + 1, dtype=torch.float32,
-                                              device=dev)
-        # Debug aid (tests): PI_MI355_POISON_UNREACHED=1 overwrites, after every exchange, all of
-        # V' that this rank neither owns nor declared reachable with NaN — a read outside the
-        # planned band then poisons the result instead of silently using stale data.
-        self._poison = None
-        if os.environ.get("PI_MI355_POISON_UNREACHED") == "1":
-            keep = torch.zeros(self._n_pad, dtype=torch.bool, device=dev)
-            keep[self._s_begin:self._s_end] = True
-            for p in np.flatnonzero(mine):
-                keep[int(p) * stride0:min((int(p) + 1) * stride0, n)] = True
-            self._poison = ~keep
-        logger.info(f"halo exchange: rank {self._rank} receives {recv[self._rank] * 4 / 2**20:.1f} MiB "
-                    f"per sweep instead of {full * 4 / 2**20:.1f} MiB")
-
-    def _start_exchange(self, full) -> list:
-        """Post the halo sends/receives for `full`; returns the requests to wait on."""
-        import torch.distributed as dist
-        ops = []
-        for src, dst, a, b in self._segments:
-            if src == self._rank:
-                ops.append(dist.P2POp(dist.isend, full[a:b], self._peer[dst], self._process_group))
-            elif dst == self._rank:
-                ops.append(dist.P2POp(dist.irecv, full[a:b], self._peer[src], self._process_group))
-        return dist.batch_isend_irecv(ops) if ops else []
-
-    def _exchange_shards(self, full) -> None:
-        """Make the freshly swept shard of `full` visible where other ranks will read it."""
-        if self._segments is None:
-            self._all_gather_shards(full)
-            return
-        for req in self._start_exchange(full):
-            req.wait()
-        if getattr(self, "_poison", None) is not None and full.dtype.is_floating_point:
-            full[self._poison] = float("nan")
-
-    def _all_reduce_scalar(self, t, op) -> None:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=getattr(dist.ReduceOp, op), group=self._process_group)
 
     # ── policy iteration ────────────────────────────────────────────────────────────
     def _evaluation_sweeps(self, n: int, gamma: float) -> None:
         """n Jacobi sweeps under the current policy; afterwards ``d_value_function`` is the
         newest iterate and ``_d_delta`` holds the residual of the last sweep (max over ranks)."""
-        rebuild, self._records_stale = self._records_stale, False
-        if self._world == 1:
-            self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                      self.d_policy, self.d_terminal_mask, self._s_begin,
-                                      self._s_end, gamma, n, self._d_delta, rebuild=rebuild)
-            if n & 1:
-                self.d_value_function, self.d_new_value_function = (
-                    self.d_new_value_function, self.d_value_function)
+        if self._comm is not None:
+            self._comm.evaluation_sweeps(self, n, gamma)
             return
-        overlap = self._segments is not None and self._send_ranges is not None
-        for k in range(n):
-            last = k == n - 1
-            if overlap:
-                # Sweep the planes other ranks are waiting for, hand them to RCCL, and sweep the
-                # interior while they travel (RCCL runs on its own stream).
-                parts = self._d_delta_parts
-                i = 0
-                for a, b in self._send_ranges:
-                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                              self.d_policy, self.d_terminal_mask, a, b, gamma, 1,
-                                              parts[i:i + 1] if last else None, rebuild=True)
-                    i += 1
-                reqs = self._start_exchange(self.d_new_value_function)
-                for a, b in self._interior_ranges:
-                    self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                              self.d_policy, self.d_terminal_mask, a, b, gamma, 1,
-                                              parts[i:i + 1] if last else None, rebuild=True)
-                    i += 1
-                for req in reqs:
-                    req.wait()
-                if self._poison is not None:
-                    self.d_new_value_function[self._poison] = float("nan")
-                if last:
-                    if i:
-                        self._d_delta.copy_(parts[:i].max().reshape(1))
-                    else:
-                        self._d_delta.zero_()          # empty shard
-            else:
-                self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function,
-                                          self.d_policy, self.d_terminal_mask, self._s_begin,
-                                          self._s_end, gamma, 1, self._d_delta if last else None,
-                                          rebuild=rebuild and k == 0)
-                self._exchange_shards(self.d_new_value_function)
+        self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function, self.d_policy,
+                                  self.d_terminal_mask, self._s_begin, self._s_end, gamma, n,
+                                  self._d_delta)
+        if n & 1:
             self.d_value_function, self.d_new_value_function = (
                 self.d_new_value_function, self.d_value_function)
-        self._all_reduce_scalar(self._d_delta, "MAX")
 
     def _improvement_sweep(self, gamma: float) -> None:
         """One greedy improvement of this rank's shard; ``_d_changed`` = entries changed (sum
         over ranks)."""
+        if self._comm is not None:
+            self._comm.improvement_sweep(self, gamma)
+            return
         self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
                                     self._s_begin, self._s_end, gamma, self._d_changed)
-        self._records_stale = True            # the policy may have changed
-        if self._world > 1:
-            self._all_reduce_scalar(self._d_changed, "SUM")
-
-    def autotune(self) -> None:
-        """Let the backend pick its launch geometry for the evaluation sweeps on the CURRENT
-        V and policy (d_new_value_function is used as scratch and restored).  Optional: the default
-        geometry (one workgroup per 256-state chunk) was the fastest on every BASELINE config."""
-        if hasattr(self._backend, "autotune") and self._s_end > self._s_begin:
-            gamma = float(np.float32(self.config.gamma))
-            self._backend.autotune(self.d_value_function, self.d_new_value_function, self.d_policy,
-                                   self.d_terminal_mask, self._s_begin, self._s_end, gamma)
-            self.d_new_value_function.copy_(self.d_value_function)
-        self._tuned = True
 
     def policy_evaluation(self) -> float:
         """Jacobi sweeps under the current policy until the residual, looked at on sweeps
@@ -529,9 +318,6 @@ class _CudaPolicyIterationBase(abc.ABC):
         t0 = time.perf_counter()
         i = 0
         sweeps = 0
-        # d_policy / d_terminal_mask are public attributes a caller may have edited since the
-        # last evaluation: never trust transition records across calls.
-        self._records_stale = True
         while i < cfg.max_eval_iter:
             check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
             check = min(check, cfg.max_eval_iter - 1)
@@ -594,36 +380,42 @@ class _CudaPolicyIterationBase(abc.ABC):
             self._backend.value_sweep(self.d_value_function, self.d_new_value_function, self.d_policy,
                                       self.d_terminal_mask, self._s_begin, self._s_end, gamma,
                                       self._d_delta if check else None, None)
-            if self._world > 1:
-                self._exchange_shards(self.d_new_value_function)
+            if self._comm is not None:
+                self._comm.exchange(self, self.d_new_value_function)
             self.d_value_function, self.d_new_value_function = (
                 self.d_new_value_function, self.d_value_function)
             sweeps += 1
             if check:
-                if self._world > 1:
-                    self._all_reduce_scalar(self._d_delta, "MAX")
+                if self._comm is not None:
+                    self._comm.all_reduce_max(self, self._d_delta)
                 delta = float(self._d_delta.item())
                 if delta < cfg.theta:
                     break
-        self._records_stale = True
         self.stats["value_sweeps"] = self.stats.get("value_sweeps", 0) + sweeps
         return delta
 
     def save_checkpoint(self, filepath) -> None:
         """Mid-run snapshot (V, policy, counters) that `load_checkpoint` can resume from; the
-        reference can only save after run() has dropped its device arrays (:392-409)."""
+        reference can only save after run() has dropped its device arrays (:392-409).  Collective
+        on several ranks (every rank calls it); rank 0 writes, to a temporary file that is renamed
+        into place."""
+        import os
         filepath = Path(filepath).with_suffix(".npz")
-        filepath.parent.mkdir(parents=True, exist_ok=True)
         n = self.n_states
-        if self._world > 1:
-            self._all_gather_shards(self.d_policy)
-            self._all_gather_shards(self.d_value_function)
-        np.savez(filepath, value_function=self.d_value_function[:n].cpu().numpy(),
-                 policy=self.d_policy[:n].cpu().numpy(), grid_shape=self.grid_shape,
-                 action_space=self.action_space,
-                 eval_sweeps=np.int64(self.stats["eval_sweeps"]),
-                 improve_sweeps=np.int64(self.stats["improve_sweeps"]),
-                 pi_iterations=np.int64(self.stats["pi_iterations"]))
+        if self._comm is not None:
+            self._comm.all_gather(self, self.d_policy)
+            self._comm.all_gather(self, self.d_value_function)
+        if self._rank == 0:
+            filepath.parent.mkdir(parents=True, exist_ok=True)
+            tmp = filepath.with_name(filepath.name + f".tmp{os.getpid()}.npz")
+            np.savez(tmp, value_function=self.d_value_function[:n].cpu().numpy(),
+                     policy=self.d_policy[:n].cpu().numpy(), grid_shape=self.grid_shape,
+                     action_space=self.action_space,
+                     eval_sweeps=np.int64(self.stats["eval_sweeps"]),
+                     improve_sweeps=np.int64(self.stats["improve_sweeps"]),
+                     pi_iterations=np.int64(self.stats["pi_iterations"]),
+                     sweeps_per_iter=np.asarray(self.stats["sweeps_per_iter"], dtype=np.int64))
+            os.replace(tmp, filepath)
 
     def load_checkpoint(self, filepath) -> None:
         """Restore V and the policy of a `save_checkpoint` file into this (freshly constructed)
@@ -639,14 +431,15 @@ class _CudaPolicyIterationBase(abc.ABC):
         self.d_policy[:n].copy_(torch.from_numpy(data["policy"]).to(dev))
         for key in ("eval_sweeps", "improve_sweeps", "pi_iterations"):
             self.stats[key] = int(data[key])
-        self._records_stale = True
+        if "sweeps_per_iter" in data:
+            self.stats["sweeps_per_iter"] = [int(x) for x in data["sweeps_per_iter"]]
 
     def _pull_tensors_from_gpu(self) -> None:
         """Copy V and the policy to host arrays and drop every device array (:372-388)."""
         logger.info("Pulling results from device memory...")
-        if self._world > 1:
-            self._all_gather_shards(self.d_policy)
-            self._all_gather_shards(self.d_value_function)     # halo mode: V is only local + halos
+        if self._comm is not None:
+            self._comm.all_gather(self, self.d_policy)
+            self._comm.all_gather(self, self.d_value_function)    # halo mode: V is only local + halos
         n = self.n_states
         self.value_function = self.d_value_function[:n].cpu().numpy()
         self.policy = self.d_policy[:n].cpu().numpy()
@@ -654,6 +447,8 @@ class _CudaPolicyIterationBase(abc.ABC):
                      "_d_delta", "_d_changed"]:
             if hasattr(self, attr):
                 delattr(self, attr)
+        if self._comm is not None:
+            self._comm.close()
         self._backend.close()
         logger.success("Device memory released. Results in host memory.")
 

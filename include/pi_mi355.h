@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 1
+#define PI_MI355_ABI_VERSION 2
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -87,44 +87,18 @@ int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* poli
                   float* d_delta, void* stream);
 
 /*
- * Pick the number of workgroups per CU for the evaluation sweeps by timing them on the caller's
- * own V / policy (candidates 2..8; the gather-bound sweeps prefer few states in flight per XCD,
- * the arithmetic-bound ones prefer occupancy — it depends on the env and on the policy).
- * Vscratch is overwritten.  BLOCKS on the stream (event synchronise): call it outside any timed
- * or captured region.  No-op when PI_MI355_EVAL_BLOCKS_PER_CU pins the value or the range is small.
- */
-int pi_autotune_eval(pi_handle* h, const float* V, float* Vscratch, const int32_t* policy,
-                     const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma, void* stream);
-
-/*
  * n_sweeps evaluation sweeps ping-ponging between Va and Vb (sweep 0 reads Va and
  * writes Vb, sweep 1 reads Vb, ...) — the body of policy_evaluation's loop between
  * two host checks (:305-331, SYNC_INTERVAL = 25).  d_delta (nullable) receives the
  * residual of the LAST sweep only, which is the only one the reference looks at.
  * The newest iterate is in Vb when n_sweeps is odd, in Va when even.
+ * Ranges of up to 2^20 states are launch-bound (a few microseconds per sweep): there the whole
+ * batch, including the residual fold, is replayed as ONE hipGraph (built on first use per
+ * argument set, cached in the handle) instead of n_sweeps host launches.
  */
 int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
                    const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,
                    int n_sweeps, float* d_delta, void* stream);
-
-/*
- * Policy evaluation with TRANSITION RECORDS (MI355X-first; no counterpart in the reference,
- * same results bit for bit).  Between two policy improvements the policy is fixed, so the
- * transition of every state — reward, interpolation cell, fractional offsets — is the same in
- * every sweep of policy_evaluation's loop (:305-331).  With rebuild != 0 the first sweep runs
- * step_dynamics as usual and also writes (2 + D) * 4 bytes per state into `cache`; every
- * later sweep (and later calls with rebuild = 0) replays those records and only gathers V.
- *   cache, cache_bytes : caller-owned device workspace, 16-byte aligned, at least
- *                        pi_transition_cache_bytes(h, s_begin, s_end) bytes.
- *   rebuild            : must be non-zero on the first call after `policy`, `term`, the
- *                        range or the cache buffer changed (the library checks the last two).
- * Ping-pong and d_delta semantics as pi_eval_sweeps.  Va / Vb must be 16-byte aligned.
- */
-size_t pi_transition_cache_bytes(pi_handle* h, int64_t s_begin, int64_t s_end);
-int pi_eval_sweeps_cached(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
-                          const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,
-                          int n_sweeps, int rebuild, void* cache, size_t cache_bytes,
-                          float* d_delta, void* stream);
 
 /*
  * Greedy improvement over [s_begin, s_end): policy[s] = argmax_a Q(s, a), first
@@ -150,14 +124,73 @@ int pi_value_sweep(pi_handle* h, const float* V, float* Vnew, int32_t* policy, c
                    void* stream);
 
 /*
- * Which dimension-0 planes of V can the states of [s_begin, s_end) read, under ANY action?
- * d_bitmap (device, ceil(grid_shape[0] / 32) uint32 words, zeroed here) receives one bit per
- * plane: the plane of every successor cell and the plane above it.  No counterpart in the
- * reference (it has no multi-GPU path); the multi-GPU host uses it to exchange only reachable
- * planes between ranks instead of all-gathering V after every sweep.
+ * Which planes of V can the states of [s_begin, s_end) read, under ANY action?  Along dimension
+ * `dim`: d_bitmap (device, ceil(grid_shape[dim] / 32) uint32 words, zeroed here) receives one bit
+ * per index: that of every successor cell and the one above it.  No counterpart in the reference
+ * (it has no multi-GPU path); the multi-GPU plan uses dim = 0 to exchange only reachable planes
+ * between ranks instead of all-gathering V after every sweep; the other
+ * dimensions tell how wide a halo a shard along them would need.
  */
-int pi_reach_planes(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end,
+int pi_reach_planes(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end, int dim,
                     uint32_t* d_bitmap, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU, RCCL over xGMI).  SURVEY.md section 8b/8e: the reference is a
+ * single-device loop (:300-336), so these entry points have no line to replace — they are what a
+ * maintainer binds to run the same loop over several GPUs.  Partition: rank r owns the contiguous
+ * state range [r * per, min((r + 1) * per, n)), per = ceil(n / world); every rank keeps full-size
+ * V buffers of per * world floats.
+ * ------------------------------------------------------------------------------------------- */
+
+/* 128-byte RCCL id: created once (any rank), handed to every rank out of band. */
+int pi_comm_unique_id(void* id128);
+/* Join the RCCL communicator on the handle's device (collective: every rank calls it). */
+int pi_comm_init(pi_handle* h, int rank, int world, const void* id128);
+/* In-process transport for tests: `world` handles of ONE process, one host thread each, exchange
+ * through device-to-device copies ordered by HIP events — same stream semantics as RCCL. */
+int pi_comm_init_local(pi_handle* h, int rank, int world, const char* group_name);
+int pi_comm_destroy(pi_handle* h);
+/* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process), 3 plan (0 none, 1 all-gather, 2 halo). */
+int pi_comm_info(pi_handle* h, int what);
+
+/* In-place collectives on the caller's stream: shard r of the buffer lives at r * shard_elems. */
+int pi_allgather_V(pi_handle* h, float* V_full, int64_t shard_elems, void* stream);
+int pi_allgather_policy(pi_handle* h, int32_t* policy_full, int64_t shard_elems, void* stream);
+int pi_allreduce_max_f32(pi_handle* h, float* d_value, void* stream);
+int pi_allreduce_sum_u32(pi_handle* h, uint32_t* d_value, void* stream);
+
+/*
+ * Pure host logic (needs no GPU and no communicator): which pieces of V' travel after a sweep.
+ *   reach[r * g0 + p] != 0  <=>  rank r's shard can read dimension-0 plane p
+ * Writes up to `cap` segments {src, dst, a, b} ("src sends V'[a, b) to dst") and returns how many
+ * there are (-1 on bad arguments).  Every rank derives the same list from the same bitmaps.
+ */
+int64_t pi_plan_segments(int world, int64_t g0, int64_t stride0, int64_t n_states, int64_t per,
+                         const uint8_t* reach, int64_t* segs, int64_t cap);
+
+/*
+ * Collective: measure this shard's reach (pi_reach_planes, dim 0), all-gather the bitmaps, derive
+ * the segments and choose the exchange.  mode 0 = choose (halo unless some rank would receive more
+ * than 60 % of an all-gather), 1 = all-gather, 2 = halo; overlap != 0 sweeps the planes peers
+ * wait for first and sends them on a second stream while the interior is swept.
+ * info (nullable, 5 values): mode chosen (1 | 2), elements received / sent per sweep by this rank,
+ * number of send ranges, number of interior ranges.  Blocks on `stream` (one-off).
+ */
+int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, int overlap,
+                     int64_t* info, void* stream);
+/* Make this rank's freshly written shard of V_full visible where the other ranks read it. */
+int pi_exchange_V(pi_handle* h, float* V_full, void* stream);
+/*
+ * pi_eval_sweeps over this rank's shard with the exchange after every sweep — the 25-sweep batch
+ * between two host checks (:305-331) without returning to the host.  d_delta (nullable) receives
+ * the residual of the last sweep, already MAX-reduced over all ranks.
+ */
+int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
+                           const uint8_t* term, float gamma, int n_sweeps, float* d_delta,
+                           void* stream);
+/* pi_improve_sweep over this rank's shard; d_changed (nullable) is SUM-reduced over all ranks. */
+int pi_improve_sweep_sharded(pi_handle* h, const float* V, int32_t* policy, const uint8_t* term,
+                             float gamma, uint32_t* d_changed, void* stream);
 
 /*
  * Probes used by the parity tests (not on the hot path): run the compiled plugin /
@@ -165,17 +198,25 @@ int pi_reach_planes(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t 
  *   pi_probe_step   : states (m,D), acts (m) -> next (m,D), reward (m), done (m)
  *   pi_probe_interp : pts (m,D) -> idxs (m,2^D) int32, wgts (m,2^D) float
  *                     (get_barycentric_{2,4,6}d, reference corner order)
+ *   pi_probe_coords : out[(s - s_begin) * D + d] = coordinate d of grid node s, computed the way
+ *                     the sweeps compute it (scalar chunk origin + per-lane carries), with
+ *                     `chunks_per_workgroup` chunks per workgroup — states_space[s] of :84-87
  */
 int pi_probe_step(pi_handle* h, const float* states, const float* acts, float* next,
                   float* reward, uint8_t* done, int64_t m, void* stream);
 int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, int64_t m,
                     void* stream);
+int pi_probe_coords(pi_handle* h, int64_t s_begin, int64_t s_end, float* out, int chunks_per_workgroup,
+                    void* stream);
 
-/* Introspection: 0 n_states, 1 n_actions, 2 D, 3 workgroups per launch,
- * 4 VGPRs of the eval kernel, 5 VGPRs of the improve kernel, 6 compute units,
- * 7 = 1 if the last pi_compile was served from the cache, 8 VGPRs of the replay kernel,
- * 9 states per thread of the replay kernel, 10 tiled kernels loaded, 12 / 13 workgroups per CU
- * of the evaluation / improvement sweeps, 20+d box extent, 30+d tile extent, 40+d reach. */
+/* Tuning: 0 = 256-state chunks per workgroup of the evaluation sweeps, 1 = of the improvement /
+ * value sweeps (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1). */
+int pi_set_option(pi_handle* h, int what, int64_t value);
+
+/* Introspection: 0 n_states, 1 n_actions, 2 D, 3 chunks per workgroup (evaluation), 4 VGPRs of the
+ * eval kernel, 5 VGPRs of the improve kernel, 6 compute units, 7 = 1 if the last pi_compile was
+ * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
+ * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
 
 #ifdef __cplusplus

@@ -1,10 +1,14 @@
 """
-Multi-rank host path on CPU: world_size 2 and 3 over gloo (the GPU path is the same code
-with backend "nccl" = RCCL).  Each rank sweeps its contiguous state shard (sizes NOT
-divisible by the world size, so the padded tail is exercised), the V shards are
-all-gathered after every evaluation sweep, residual / changed-count are all-reduced, and the
-result must be bit-identical to the single-rank run.  The sweep backend is
-the CPU checker injected through ``backend_factory`` (test-only).
+Multi-rank host path on CPU: world_size 2, 3 and 4 over gloo.  On the GPU the exchange runs
+inside libpi_mi355.so over RCCL (csrc/pi_comm.cpp, tested with its in-process transport in
+tests/test_gpu_parity.py); here the SAME plan — the library's host-only ``pi_plan_segments`` —
+is driven from Python by the test transport (``transport.TorchDistTransport``).  Each rank
+sweeps its contiguous state shard (sizes NOT divisible by the world size, so the padded tail
+is exercised), the reachable planes (or the whole shards) travel after every evaluation sweep,
+residual / changed-count are all-reduced, and the result must be bit-identical to the
+single-rank run.  Everything a rank did not declare reachable is poisoned with
+NaN after each exchange, so a plan that misses a plane cannot pass.  The sweep backend is the
+CPU checker injected through ``backend_factory`` (test-only).
 """
 from __future__ import annotations
 
@@ -48,8 +52,7 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
                  sweeps=np.asarray(s.stats["sweeps_per_iter"]), evals=s._backend.calls["eval"],
-                 halo=np.int64(-1 if s._segments is None else
-                               sum(b - a for (_, d, a, b) in s._segments if d == rank)))
+                 halo=np.int64(s._comm.halo_elems))
     finally:
         dist.destroy_process_group()
 

@@ -20,14 +20,6 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["flat", "tiled"])
-def kernel_family(request, monkeypatch):
-    """Every parity test runs against both evaluation-kernel families: the flat
-    one-state-per-lane sweeps and the tile-staged (LDS box) sweeps."""
-    monkeypatch.setenv("PI_MI355_TILED", "1" if request.param == "tiled" else "0")
-    return request.param
-
-
 def _torch():
     import torch
     return torch
@@ -333,99 +325,6 @@ def test_error_paths(cuda_device):
     bad.close()
 
 
-# ── transition records (pi_eval_sweeps_cached) ─────────────────────────────────────────
-def _cached_case(name, shape, dev, seed, spt, monkeypatch):
-    monkeypatch.setenv("PI_MI355_SPT", str(spt))
-    eng, acts, meta, states, term, V, pol = _sweep_case(name, shape, dev, seed)
-    assert eng.info(9) == spt
-    return eng, acts, meta, states, term, V, pol
-
-
-@pytest.mark.parametrize("spt", [1, 2, 4])
-@pytest.mark.parametrize("name,shape", [("pendulum", (33, 29)), ("mountain_car", (40, 23)),
-                                         ("cartpole", (9, 7, 11, 5)),
-                                         ("double_pendulum_swingup", (12, 11, 13, 10)),
-                                         ("overhead_crane", (9, 7, 9, 7)),
-                                         ("double_cartpole", (5, 4, 6, 4, 5, 4))])
-def test_cached_evaluation_is_bit_identical(name, shape, spt, cuda_device, monkeypatch):
-    """Recording the transitions on sweep 0 and replaying them gives exactly the V of
-    recomputing the dynamics every sweep (oracle), for full ranges, ragged shard ranges that
-    start/end off the 4-state alignment, terminal nodes and terminating transitions."""
-    torch = _torch()
-    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _cached_case(
-        name, shape, cuda_device, 11, spt, monkeypatch)
-    n = len(V)
-    gamma = float(np.float32(envs.ENVS[name].CONFIG["gamma"]))
-    chk = H.oracle_for(name)
-    d_pol = _dev(pol, cuda_device)
-    d_term = _dev(term.astype(np.uint8), cuda_device)
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    for a, b in [(0, n), (1, n - 2), (n // 3 + 1, 2 * n // 3 + 3), (5, 6), (n - 3, n)]:
-        need = eng.transition_cache_bytes(a, b)
-        assert need >= (b - a) * (2 + len(shape)) * 4
-        cache = torch.empty(need, dtype=torch.uint8, device=cuda_device)
-        d_A, d_B = _dev(V, cuda_device), torch.full((n,), -5.0, dtype=torch.float32, device=cuda_device)
-        with pytest.raises(_native.NativeError, match="rebuild"):
-            eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
-                                   a, b, gamma, 1, False, cache.data_ptr(), need, d_delta.data_ptr())
-        eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
-                               a, b, gamma, 4, True, cache.data_ptr(), need, d_delta.data_ptr())
-        torch.cuda.synchronize()
-        # oracle: 4 sweeps restricted to [a, b); outside the range both buffers keep their values
-        oA, oB = V.copy(), np.full(n, -5.0, dtype=np.float32)
-        for i in range(4):
-            src, dst = (oB, oA) if i & 1 else (oA, oB)
-            _, o_delta = chk.eval_sweep(states, acts, pol, src, term, lo, hi, gshape, strides, gamma,
-                                        a, b, out=dst)
-        H.assert_bits_equal(d_A.cpu().numpy(), oA, f"{name} [{a},{b}) buffer A")
-        H.assert_bits_equal(d_B.cpu().numpy(), oB, f"{name} [{a},{b}) buffer B")
-        assert np.float32(d_delta.item()) == np.float32(o_delta)
-        # continue without rebuilding: 3 more sweeps replay the same records
-        eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
-                               a, b, gamma, 3, False, cache.data_ptr(), need, d_delta.data_ptr())
-        torch.cuda.synchronize()
-        for i in range(3):
-            src, dst = (oB, oA) if i & 1 else (oA, oB)
-            _, o_delta = chk.eval_sweep(states, acts, pol, src, term, lo, hi, gshape, strides, gamma,
-                                        a, b, out=dst)
-        H.assert_bits_equal(d_A.cpu().numpy(), oA, "A after replay-only call")
-        H.assert_bits_equal(d_B.cpu().numpy(), oB, "B after replay-only call")
-        assert np.float32(d_delta.item()) == np.float32(o_delta)
-        with pytest.raises(_native.NativeError, match="too small"):
-            eng.eval_sweeps_cached(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(),
-                                   a, b, gamma, 1, True, cache.data_ptr(), need - 16, 0)
-    eng.close()
-
-
-def test_solver_with_and_without_transition_cache_agree(cuda_device):
-    """Full run() on a 4-D problem with terminal states, cache on vs off: identical V, policy and
-    sweep counts (and both equal the oracle's run)."""
-    name, shape = "cartpole", (12, 10, 14, 10)
-    cls = envs.ENVS[name]
-    res = []
-    for cache in (True, False):
-        cfg = envs.CudaPIConfig(**{**cls.CONFIG, "max_pi_iter": 6, "max_eval_iter": 400},
-                                cache_transitions=cache)
-        s = cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device)
-        assert (getattr(s._backend, "_cache", None) is not None) == cache
-        s.run()
-        res.append(s)
-    assert res[0].stats["sweeps_per_iter"] == res[1].stats["sweeps_per_iter"]
-    assert np.array_equal(res[0].policy, res[1].policy)
-    H.assert_bits_equal(res[0].value_function, res[1].value_function, "cache on/off")
-    bins = H.env_bins(name, shape)
-    lo, hi, gshape, strides = oracle.grid_metadata(bins)
-    states = oracle.states_from_bins(bins)
-    term, tval = H.terminal_mask(name, states)
-    cfg = res[0].config
-    ref = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, gamma=cfg.gamma,
-                                 theta=cfg.theta, max_eval_iter=cfg.max_eval_iter,
-                                 max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
-    assert res[0].stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
-    assert np.array_equal(res[0].policy, ref["policy"])
-    H.assert_bits_equal(res[0].value_function, ref["value_function"], "vs oracle")
-
-
 @pytest.mark.parametrize("name,shape", [("pendulum", (41, 13)), ("double_pendulum_swingup", (20, 9, 10, 9)),
                                          ("double_cartpole", (6, 4, 5, 4, 5, 4))])
 def test_reach_planes_matches_cpu_restatement(name, shape, cuda_device):
@@ -477,35 +376,10 @@ def test_value_sweep_bit_exact(name, shape, cuda_device):
     eng.close()
 
 
-def test_autotune_changes_geometry_not_results(cuda_device):
-    """pi_autotune_eval picks a workgroups-per-CU setting by timing; whatever it picks, the sweep
-    stays bit-identical to the oracle."""
-    torch = _torch()
-    name, shape = "cartpole", (30, 30, 30, 30)
-    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, 9)
-    n = len(V)
-    d_V, d_pol = _dev(V, cuda_device), _dev(pol, cuda_device)
-    d_term = _dev(term.astype(np.uint8), cuda_device)
-    d_Vn = torch.empty_like(d_V)
-    picked = eng.autotune_eval(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99)
-    assert picked in (2, 3, 4, 6, 8, 4096)
-    d_Vn.fill_(float("nan"))
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, 0.99,
-                   d_delta.data_ptr())
-    torch.cuda.synchronize()
-    o_Vn, o_delta = H.oracle_for(name).eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, 0.99)
-    H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "V' after autotune")
-    assert np.float32(d_delta.item()) == np.float32(o_delta)
-    eng.close()
-
-
-def test_full_size_c5_properties(cuda_device, kernel_family):
+def test_full_size_c5_properties(cuda_device):
     """BASELINE config C5 (double cartpole 25^6 = 244 140 625 states, n odd) at full size on one
     GPU: residual, shard invariance with the ragged 8-way split the multi-GPU path uses, terminal
     states copied, oracle windows (64-corner interpolation, int32 indices near 2^28)."""
-    if kernel_family == "tiled":
-        pytest.skip("full-size 6-D check runs on the default (flat) kernels")
     torch = _torch()
     name, shape = "double_cartpole", (25,) * 6
     eng, bins, acts = _engine(name, shape, cuda_device)
@@ -564,12 +438,10 @@ def test_full_size_c5_properties(cuda_device, kernel_family):
 
 
 @pytest.mark.parametrize("name,bins", [("double_pendulum_swingup", 15), ("double_cartpole", 7)])
-def test_full_run_4d_6d_matches_oracle(name, bins, cuda_device, kernel_family):
+def test_full_run_4d_6d_matches_oracle(name, bins, cuda_device):
     """End-to-end run() with the env's own settings on a 4-D grid (15^4, the reference runner's
     default; ~66 000 sweeps of wrap- and trig-heavy dynamics) and a 6-D grid: V, policy and the
     sweep count of every outer iteration equal the oracle's run."""
-    if kernel_family == "tiled":
-        pytest.skip("long run: default kernel family only")
     cls = envs.ENVS[name]
     cfg = envs.CudaPIConfig(**cls.CONFIG)
     solver = envs.make(name, bins, device=cuda_device)
@@ -585,3 +457,219 @@ def test_full_run_4d_6d_matches_oracle(name, bins, cuda_device, kernel_family):
     assert solver.stats.get("stable") == ref["stable"]
     assert np.array_equal(solver.policy, ref["policy"])
     H.assert_bits_equal(solver.value_function, ref["value_function"], f"{name} full run V")
+
+
+# ── launch geometry, graphs, guards ─────────────────────────────────────────────────────
+@pytest.mark.parametrize("name,shape", [("pendulum", (200, 200)), ("double_pendulum_swingup", (13, 9, 11, 17)),
+                                         ("double_cartpole", (5, 4, 6, 3, 5, 7))])
+def test_chunks_per_workgroup_change_speed_not_results(name, shape, cuda_device):
+    """A workgroup sweeps `cpw` consecutive 256-state chunks with the next chunk's inputs
+    prefetched; whatever cpw is (1 .. more chunks than the range has), V', policy, residual and
+    changed-count are the oracle's, on ragged sub-ranges too.  Also checks the coordinate probe
+    (pi_state_coords as the sweeps walk it) against states_space."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, seed=21)
+    n = len(states)
+    chk = H.oracle_for(name)
+    gamma = float(np.float32(0.97))
+    d_V, d_pol, d_term = _dev(V, cuda_device), _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    for a, b in ((0, n), (n // 7 + 3, n - n // 5 - 1), (5, 6), (n - 300, n)):
+        a, b = max(a, 0), min(b, n)
+        o_Vn, o_delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma, a, b)
+        o_pol, o_changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma, a, b)
+        for cpw in (1, 2, 3, 8, 64):
+            eng.set_option(0, cpw)
+            eng.set_option(1, cpw)
+            d_Vn = d_V.clone()
+            eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b,
+                           gamma, d_delta.data_ptr())
+            H.assert_bits_equal(d_Vn.cpu().numpy()[a:b], o_Vn[a:b], f"V' cpw={cpw} [{a},{b})")
+            assert np.array_equal(d_Vn.cpu().numpy()[:a], V[:a]) and np.array_equal(d_Vn.cpu().numpy()[b:], V[b:])
+            H.assert_bits_equal(np.float32(d_delta.item()), np.float32(o_delta), "residual")
+            d_p2 = d_pol.clone()
+            eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), a, b, gamma,
+                              d_changed.data_ptr())
+            assert np.array_equal(d_p2.cpu().numpy()[a:b], o_pol[a:b])
+            assert np.array_equal(d_p2.cpu().numpy()[:a], pol[:a]) and np.array_equal(d_p2.cpu().numpy()[b:], pol[b:])
+            assert int(d_changed.item()) == o_changed
+            out = torch.full(((b - a) * len(shape),), float("nan"), dtype=torch.float32, device=cuda_device)
+            eng.probe_coords(a, b, out.data_ptr(), cpw)
+            H.assert_bits_equal(out.cpu().numpy().reshape(-1, len(shape)), states[a:b], "state coordinates")
+    eng.close()
+
+
+def test_small_batches_replay_as_graphs(cuda_device):
+    """pi_eval_sweeps on a launch-bound range builds one hipGraph per argument set and replays it;
+    results equal the eager launches' (graphs off) bit for bit, for both ping-pong orders."""
+    torch = _torch()
+    name, shape = "pendulum", (64, 48)
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, seed=3)
+    n = len(states)
+    gamma = float(np.float32(0.99))
+    d_pol, d_term = _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
+    results = {}
+    for graphs in (1, 0):
+        eng.set_option(2, graphs)
+        A, B = _dev(V, cuda_device), torch.zeros(n, dtype=torch.float32, device=cuda_device)
+        d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+        deltas = []
+        for rep in range(3):                       # 25 + 25 + 25 sweeps: the same graph replayed
+            eng.eval_sweeps(A.data_ptr(), B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                            25, d_delta.data_ptr())
+            A, B = B, A                            # odd batch: newest iterate is in B
+            deltas.append(float(d_delta.item()))
+        results[graphs] = (A.cpu().numpy(), B.cpu().numpy(), deltas)
+        if graphs:
+            assert eng.info(9) == 2                # (A,B) and (B,A)
+        else:
+            assert eng.info(10) == 0
+    H.assert_bits_equal(results[1][0], results[0][0], "newest iterate, graph vs eager")
+    H.assert_bits_equal(results[1][1], results[0][1], "previous iterate, graph vs eager")
+    assert results[1][2] == results[0][2]
+    chk = H.oracle_for(name)
+    a, b = V.copy(), np.zeros_like(V)
+    for _ in range(75):
+        b, dl = chk.eval_sweep(states, acts, pol, a, term, lo, hi, gshape, strides, gamma, 0, n)
+        a, b = b, a
+    H.assert_bits_equal(results[1][0], a, "75 sweeps vs the oracle")
+    eng.close()
+
+
+def test_interpolation_division_guard_edges(cuda_device):
+    """The reciprocal-multiply division of the interpolation is only taken for 2^-40 <= |s - lo|
+    and sum |s - lo| < 2^40; zero, denormal, huge, infinite and NaN coordinates must take the IEEE
+    path and land where the reference's arithmetic puts them (indices exact, weights bit-exact)."""
+    torch = _torch()
+    name, shape = "cartpole", (9, 7, 11, 5)
+    eng, bins, acts = _engine(name, shape, cuda_device)
+    assert [eng.info(20 + d) for d in range(4)] == [1, 1, 1, 1]
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    rng = np.random.default_rng(5)
+    pts = H.sample_states(rng, bins, 4096)
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-30, 3e-13, 1e12, 1.2e12, 3e38, -3e38,
+                         np.inf, -np.inf, np.nan], dtype=np.float32)
+    for k, v in enumerate(specials):              # each special in each dimension, alone and together
+        for d in range(4):
+            pts[16 * k + d, d] = lo[d] + v if np.isfinite(v) and abs(v) < 1e20 else v
+        pts[16 * k + 4, :] = v
+        pts[16 * k + 5, :] = lo            # s - lo == 0 exactly
+        pts[16 * k + 6, :] = hi
+    chk = H.oracle_for(name)
+    o_idx, o_w = chk.interp(pts, lo, hi, gshape, strides)
+    d_pts = _dev(pts, cuda_device)
+    d_idx = torch.zeros((len(pts), 16), dtype=torch.int32, device=cuda_device)
+    d_w = torch.zeros((len(pts), 16), dtype=torch.float32, device=cuda_device)
+    eng.probe_interp(d_pts.data_ptr(), d_idx.data_ptr(), d_w.data_ptr(), len(pts))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_idx.cpu().numpy(), o_idx)
+    got, want = d_w.cpu().numpy(), o_w
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), np.argwhere(~same)[:5]
+    eng.close()
+
+
+# ── the sharded driver of the library over the in-process transport ─────────────────────
+@pytest.mark.parametrize("mode", ["halo", "allgather"])
+@pytest.mark.parametrize("world,name,shape", [(2, "pendulum", (41, 13)),
+                                               (3, "double_pendulum_swingup", (14, 9, 11, 8)),
+                                               (2, "double_cartpole", (6, 4, 5, 4, 5, 4))])
+def test_sharded_driver_local_transport(world, name, shape, mode, cuda_device, monkeypatch):
+    """pi_eval_sweeps_sharded / pi_improve_sweep_sharded / pi_exchange_plan (csrc/pi_comm.cpp) with
+    `world` logical ranks on ONE GPU: one host thread, one stream, one set of V buffers per rank,
+    exchanging through the in-process transport (device copies ordered by HIP events, the
+    stream semantics of RCCL send/recv).  Exercises the overlap path with real kernels: planes
+    peers wait for swept first, exchange on the second stream, interior meanwhile.  Every rank's
+    run() must equal the single-rank run bit for bit."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_EXCHANGE", mode)
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 3, "max_eval_iter": 60}
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
+    single.run()
+    group = f"test-{uuid.uuid4().hex}"
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            stream = torch.cuda.Stream(device=cuda_device)
+            with torch.cuda.stream(stream):
+                s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw),
+                        device=cuda_device, transport=T.NativeTransport.local(r, world, group))
+                info = dict(s._comm.info)
+                s.run()
+            out[r] = (s.value_function, s.policy, list(s.stats["sweeps_per_iter"]), info)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(o is not None for o in out), "a rank did not finish"
+    for r in range(world):
+        V, pol, sweeps, info = out[r]
+        H.assert_bits_equal(V, single.value_function, f"rank {r} V")
+        assert np.array_equal(pol, single.policy)
+        assert sweeps == single.stats["sweeps_per_iter"]
+        assert info["mode"] == mode
+        if mode == "halo":
+            assert info["send_ranges"] >= 1 and 0 < info["recv_elems"] < (world - 1) * -(-single.n_states // world)
+
+
+def test_full_size_c3_properties(cuda_device):
+    """BASELINE config C3 (cartpole swing-up 50^4 = 6.25 M states x 5 actions) at full size:
+    residual, shard invariance, terminal states copied, linearity in V, oracle windows."""
+    torch = _torch()
+    name, shape = "cartpole_swingup", (50,) * 4
+    eng, bins, acts = _engine(name, shape, cuda_device)
+    n = 50 ** 4
+    gamma = float(np.float32(0.999))
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    V = torch.randn(n, generator=gen, dtype=torch.float32)
+    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
+    states = oracle.states_from_bins(bins)
+    term_np, _ = H.terminal_mask(name, states)
+    assert term_np.any()
+    d_V, d_pol = V.to(cuda_device), pol.to(cuda_device)
+    d_term = _dev(term_np.astype(np.uint8), cuda_device)
+    d_Vn = torch.empty_like(d_V)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                   d_delta.data_ptr())
+    torch.cuda.synchronize()
+    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
+    tmask = d_term.bool()
+    assert torch.equal(d_Vn[tmask], d_V[tmask])
+    per = -(-n // 3)
+    d_Vs = torch.empty_like(d_V)
+    for r in range(3):
+        a, b = min(r * per, n), min((r + 1) * per, n)
+        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_Vs, d_Vn)
+    # the backup is affine in V: T(V + c) - T(V) = gamma * c on non-terminal, non-terminating states
+    d_V2 = d_V + 8.0
+    d_Vn2 = torch.empty_like(d_V)
+    eng.eval_sweep(d_V2.data_ptr(), d_Vn2.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
+    diff = (d_Vn2 - d_Vn)[~tmask]
+    assert float((diff - 8.0 * gamma).abs().max().item()) < 2e-5 or float(diff.min().item()) >= 0.0
+    chk = H.oracle_for(name)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    Vh, polh = V.numpy(), pol.numpy()
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    for a, b in ((0, 70_000), (n // 2 - 5, n // 2 + 50_000), (n - 60_001, n)):
+        o_Vn, _ = chk.eval_sweep(states, acts, polh, Vh, term_np, lo, hi, gshape, strides, gamma, a, b)
+        H.assert_bits_equal(d_Vn[a:b].cpu().numpy(), o_Vn[a:b], f"C3 window [{a},{b})")
+        d_p2 = d_pol.clone()
+        eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), a, b, gamma, d_changed.data_ptr())
+        o_pol, o_changed = chk.improve_sweep(states, acts, polh, Vh, term_np, lo, hi, gshape, strides, gamma, a, b)
+        assert np.array_equal(d_p2[a:b].cpu().numpy(), o_pol[a:b])
+        assert int(d_changed.item()) == o_changed
+    eng.close()

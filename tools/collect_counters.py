@@ -1,0 +1,86 @@
+"""tools/collect_counters.py OUTDIR LABEL [LABEL...] — fold the rocprofv3 passes that
+tools/profile_counters.sh wrote under OUTDIR/<label>_<pass>/ into one JSON per label:
+per kernel, the mean over the last `PI_LAST` (default 20) dispatches of every counter, the mean
+kernel duration from the kernel trace of the same passes, and the derived figures the roofline
+needs (VALU instructions per wave, busy fraction, L2 hit rate, HBM-side bytes with the gfx950
+FETCH_SIZE correction of MI355X_MICROARCH.md section HBM: x2 for the streaming reads, calibrated
+by the identity-dynamics pass when present).
+"""
+import collections, csv, glob, json, os, subprocess, sys
+
+out = sys.argv[1]
+labels = sys.argv[2:]
+LAST = int(os.environ.get("PI_LAST", "20"))
+
+
+def head_hash():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("dynamicprogramming_amd/csrc/pi_sweep_kernels.hip", "include/pi_math.h",
+                "dynamicprogramming_amd/csrc/pi_api.cpp"):
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def passes(label):
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    durations = collections.defaultdict(list)
+    for d in sorted(glob.glob(os.path.join(out, f"{label}_*"))):
+        for cf in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            rows = list(csv.DictReader(open(cf)))
+            per = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in rows:
+                if r["Kernel_Name"].startswith("pi_"):
+                    per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k, cs in per.items():
+                for c, v in cs.items():
+                    counters[k][c] = v[-LAST:]
+        for kf in glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")):
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(kf)):
+                if r["Kernel_Name"].startswith("pi_"):
+                    per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+            for k, v in per.items():
+                durations[k].extend(v[-LAST:])
+    return counters, durations
+
+
+cal = None
+for label in labels:
+    counters, durations = passes(label)
+    res = {"label": label, "kernel_source_hash": head_hash(), "dispatches_averaged": LAST, "kernels": {}}
+    for k in sorted(counters):
+        c = {name: sum(v) / len(v) for name, v in counters[k].items() if v}
+        e = {"counters": c}
+        if durations.get(k):
+            e["ms_under_profiler"] = sum(durations[k]) / len(durations[k])
+        w = c.get("SQ_WAVES")
+        if w:
+            if "SQ_INSTS_VALU" in c:
+                e["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / w
+            if "SQ_INSTS_SALU" in c:
+                e["salu_insts_per_wave"] = c["SQ_INSTS_SALU"] / w
+            if "SQ_INSTS_VMEM_RD" in c:
+                e["vmem_rd_insts_per_wave"] = c["SQ_INSTS_VMEM_RD"] / w
+            if "SQ_WAVE_CYCLES" in c:
+                e["wave_cycles_per_wave_x4"] = 4 * c["SQ_WAVE_CYCLES"] / w
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+            for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                         "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):
+                if name in c:
+                    e[name.lower() + "_frac_of_wave_cycles"] = c[name] / c["SQ_WAVE_CYCLES"]
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if "FETCH_SIZE" in c:
+            e["FETCH_SIZE_bytes"] = c["FETCH_SIZE"] * 1024.0
+        if "WRITE_SIZE" in c:
+            e["WRITE_SIZE_bytes"] = c["WRITE_SIZE"] * 1024.0
+        res["kernels"][k] = e
+    if label == "cal":
+        cal = res
+    json.dump(res, open(os.path.join(out, f"counters_{label}.json"), "w"), indent=1)
+    print(label, json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"}
+                             for k, v in res["kernels"].items()}, indent=1))
