@@ -73,6 +73,17 @@ class NativeError(RuntimeError):
     pass
 
 
+def kernel_source_hash() -> str:
+    """Fingerprint of the device code and its host driver: profiles record it so that counters
+    measured on one version of the kernels are never quoted for another (bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (_PKG / "csrc" / "pi_sweep_kernels.hip", _PKG.parent / "include" / "pi_math.h",
+                 _PKG / "csrc" / "pi_api.cpp"):
+        h.update(path.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def lib() -> ctypes.CDLL:
     """The loaded library; raises NativeError (never falls back) when unavailable."""
     global _lib, _load_error

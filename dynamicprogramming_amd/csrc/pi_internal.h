@@ -23,7 +23,7 @@ const std::string& last_error();
             return ::pi::fail(std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-constexpr int kBlock = 256;      // PI_BLOCK of the kernel template
+constexpr int kProbeBlock = 256; // threads per workgroup of the probe kernels' host launches
 constexpr int kXcds = 8;         // PI_NXCD
 constexpr int kSlots = 256;      // PI_NSLOT
 
@@ -71,7 +71,8 @@ struct pi_handle {
                   f_reach_planes = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr;
     int num_cu = 0;
-    int cpw_eval = 1, cpw_improve = 1;   // 256-state chunks a workgroup sweeps
+    int block_eval = 256, block_improve = 256;   // threads per workgroup = states per chunk
+    int cpw_eval = 1, cpw_improve = 1;           // chunks a workgroup sweeps
     int vgpr_eval = -1, vgpr_improve = -1;
     bool cache_hit = false;
     bool use_graphs = true;

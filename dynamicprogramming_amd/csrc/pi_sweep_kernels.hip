@@ -47,7 +47,16 @@
 // ties, NaN never wins).
 
 #define PI_C (1 << PI_D)
-#define PI_BLOCK 256
+// Threads per workgroup = states per chunk, per kernel family (generated: 256, 512 or 1024).
+// Big workgroups put the gathers of 4-16 adjacent waves behind ONE vector L1: their corner rows
+// overlap, which is worth 8 % on the 80^4 evaluation sweep (profiles/r02/block_cpw_sweep.txt).
+#ifndef PI_BLOCK_EVAL
+#define PI_BLOCK_EVAL 256
+#endif
+#ifndef PI_BLOCK_IMPROVE
+#define PI_BLOCK_IMPROVE 256
+#endif
+#define PI_BLOCK 256        // probes and the reach kernel
 #define PI_NXCD 8
 #define PI_NSLOT 256       // accumulator slots for the residual / the changed-count
 
@@ -211,42 +220,50 @@ __device__ __forceinline__ void pi_corner_weights(const float (&fr)[PI_D], float
 }
 
 // Two adjacent floats with 4-byte alignment: one global_load_dwordx2.
-struct __attribute__((packed, aligned(4))) PiPair { float lo, hi; };
+typedef float PiPair __attribute__((ext_vector_type(2)));
+typedef PiPair PiPairU __attribute__((aligned(4)));
+#define PI_NPAIR (PI_C / 2)
 
 // Multilinear interpolation of V over the cell.  All 2^D values are requested first — the two
 // corners along the last dimension are adjacent in memory and come as one 8-byte load — then
 // the fmaf chain runs in ascending corner order from 0.0f like the reference's.
+// vp[mb] holds the corners with slow-dimension mask mb (bits 0 .. D-2): .x = last-dim bit 0, .y = 1.
 // Addressing: a 32-bit BYTE offset from the scalar table pointer (global_load ... v, s[..]) where
 // 4 n < 2^32; corners that differ in the slow dimensions cost one 32-bit add each, the
 // second-to-last dimension rides in the instruction's immediate offset.
-__device__ __forceinline__ float pi_interpolate(const float* __restrict__ V, unsigned int base,
-                                                const float (&fr)[PI_D]) {
-    float v[PI_C];
-    constexpr int kLast = 1 << (PI_D - 1);          // mask bit of the last dimension
-    constexpr int kNear = PI_D >= 2 ? 1 << (PI_D - 2) : 0;
+__device__ __forceinline__ void pi_request_corners(const float* __restrict__ V, unsigned int base,
+                                                   PiPair (&vp)[PI_NPAIR]) {
+    constexpr int kNear = 1 << (PI_D - 2);
 #pragma unroll
-    for (int m = 0; m < PI_C; ++m) {
-        if (m & (kLast | kNear)) continue;           // m: corner mask over the slow dimensions
+    for (int m = 0; m < kNear; ++m) {                // m: corner mask over dimensions 0 .. D-3
         int far = 0;
 #pragma unroll
         for (int d = 0; d < PI_D - 2; ++d) far += ((m >> d) & 1) * PI_GRID.stride[d];
         const char* p;
         if (PI_OFF32) p = reinterpret_cast<const char*>(V) + (base * 4u + (unsigned int)far * 4u);
         else p = reinterpret_cast<const char*>(V + ((unsigned long long)base + (unsigned long long)far));
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const PiPair pr = *reinterpret_cast<const PiPair*>(p + (long)nb * PI_GRID.stride[PI_D - 2] * 4);
-            const int mask = m | (nb ? kNear : 0);
-            v[pi_corner_mask(mask)] = pr.lo;         // pi_corner_mask is its own inverse
-            v[pi_corner_mask(mask | kLast)] = pr.hi;
-        }
+        vp[m] = *reinterpret_cast<const PiPairU*>(p);
+        vp[m | kNear] = *reinterpret_cast<const PiPairU*>(p + (long)PI_GRID.stride[PI_D - 2] * 4);
     }
+}
+__device__ __forceinline__ float pi_combine_corners(const PiPair (&vp)[PI_NPAIR], const float (&fr)[PI_D]) {
+    constexpr int kLast = 1 << (PI_D - 1);
     float w[PI_C];
     pi_corner_weights(fr, w);
     float e = 0.0f;
 #pragma unroll
-    for (int c = 0; c < PI_C; ++c) e = fmaf(w[pi_corner_mask(c)], v[c], e);
+    for (int c = 0; c < PI_C; ++c) {
+        const int mask = pi_corner_mask(c);
+        const float v = (mask & kLast) ? vp[mask & (kLast - 1)].y : vp[mask & (kLast - 1)].x;
+        e = fmaf(w[mask], v, e);
+    }
     return e;
+}
+__device__ __forceinline__ float pi_interpolate(const float* __restrict__ V, unsigned int base,
+                                                const float (&fr)[PI_D]) {
+    PiPair vp[PI_NPAIR];
+    pi_request_corners(V, base, vp);
+    return pi_combine_corners(vp, fr);
 }
 
 __device__ __forceinline__ float pi_backup(const float (&s)[PI_D], float a,
@@ -287,9 +304,10 @@ __device__ __forceinline__ void pi_state_coords(unsigned int s, const float* lds
 // and because the dispatcher starts workgroups in index order the states in flight on an XCD
 // form one compact, advancing window (measured 5x less traffic past L2 than a grid-stride launch,
 // profiles/r01).  Placement only affects speed.  Returns false when the workgroup has no group.
+template <int BLOCK>
 __device__ __forceinline__ bool pi_first_chunk(long long count, int cpw, long long& chunk0,
                                                long long& n_chunks) {
-    n_chunks = (count + PI_BLOCK - 1) / PI_BLOCK;
+    n_chunks = (count + BLOCK - 1) / BLOCK;
     const long long groups = (n_chunks + cpw - 1) / cpw;
     const long long span = (groups + PI_NXCD - 1) / PI_NXCD;
     const long long x = blockIdx.x % PI_NXCD, j = blockIdx.x / PI_NXCD;
@@ -299,22 +317,23 @@ __device__ __forceinline__ bool pi_first_chunk(long long count, int cpw, long lo
 }
 
 // Bin tables and actions -> LDS.  All loads are issued before the first store.
+template <int BLOCK>
 __device__ __forceinline__ void pi_stage_table(const float* __restrict__ tab, float* lds_tab) {
-    constexpr int kPer = (PI_GRID.tab_len + PI_BLOCK - 1) / PI_BLOCK;
+    constexpr int kPer = (PI_GRID.tab_len + BLOCK - 1) / BLOCK;
     if (kPer <= 8) {
         float t[kPer];
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            const int i = j * PI_BLOCK + (int)threadIdx.x;
+            const int i = j * BLOCK + (int)threadIdx.x;
             t[j] = tab[min(i, PI_GRID.tab_len - 1)];
         }
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            const int i = j * PI_BLOCK + (int)threadIdx.x;
+            const int i = j * BLOCK + (int)threadIdx.x;
             if (i < PI_GRID.tab_len) lds_tab[i] = t[j];
         }
     } else {
-        for (int i = threadIdx.x; i < PI_GRID.tab_len; i += PI_BLOCK) lds_tab[i] = tab[i];
+        for (int i = threadIdx.x; i < PI_GRID.tab_len; i += BLOCK) lds_tab[i] = tab[i];
     }
 }
 
@@ -329,17 +348,19 @@ __device__ __forceinline__ float pi_wave_max(float v) {
 // Residual of a wave -> one of the PI_NSLOT accumulator words (bit pattern of a float >= 0
 // orders like an unsigned int; one word saturates at ~90 atomics per microsecond on MI355X,
 // hence the slots; pi_finalize_kernel folds them).
+template <int BLOCK>
 __device__ __forceinline__ void pi_wave_max_to(float dmax, unsigned int* __restrict__ delta_bits) {
     dmax = pi_wave_max(dmax);
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f)
-        atomicMax(delta_bits + ((blockIdx.x * (PI_BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)),
+        atomicMax(delta_bits + ((blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)),
                   __float_as_uint(dmax));
 }
+template <int BLOCK>
 __device__ __forceinline__ void pi_wave_sum_to(unsigned int c, unsigned int* __restrict__ slots) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c != 0u)
-        atomicAdd(slots + ((blockIdx.x * (PI_BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)), c);
+        atomicAdd(slots + ((blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (PI_NSLOT - 1)), c);
 }
 
 // Per-state inputs of a sweep, requested together so that one wait covers them.  Addresses are
@@ -374,22 +395,22 @@ __device__ __forceinline__ void pi_store_lane(T* chunk_base, unsigned int lane, 
 // ---- policy evaluation sweep ---------------------------------------------------
 // Vn[s] = r(s, pi(s)) + gamma * E[V](s')   for s in [s_begin, s_end); terminal: copy.
 // delta_bits (nullable): slots receiving the atomic max of the bit pattern of |Vn - V|.
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL)
 pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
                      const int* __restrict__ policy, const unsigned char* __restrict__ term,
                      const float* __restrict__ tab, long long s_begin, long long s_end,
                      float gamma, unsigned int* __restrict__ delta_bits, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    if (!pi_first_chunk<PI_BLOCK_EVAL>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
     const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
 
     const unsigned int tid = threadIdx.x;
-    long long sb = s_begin + chunk0 * PI_BLOCK;                     // first state of the chunk
+    long long sb = s_begin + chunk0 * PI_BLOCK_EVAL;                     // first state of the chunk
     // lanes past s_end (tail of the last chunk) shadow the last valid state and store nothing
-    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
     PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
-    pi_stage_table(tab, lds_tab);
+    pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
     __syncthreads();
 
     float dmax = 0.0f;
@@ -398,8 +419,8 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
         const long long sb_c = sb;
         const unsigned int lane_c = lane;
         if (k + 1 < n_here) {                                        // prefetch the next chunk's inputs
-            sb += PI_BLOCK;
-            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+            sb += PI_BLOCK_EVAL;
+            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
             nxt = pi_load_state(V, policy, term, sb, lane);
         }
         float nv = cur.v_old;
@@ -424,7 +445,7 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
             dmax = dlt > dmax ? dlt : dmax;
         }
     }
-    if (delta_bits != nullptr) pi_wave_max_to(dmax, delta_bits);
+    if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
 }
 
 // ---- greedy policy improvement sweep -------------------------------------------
@@ -446,14 +467,14 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
                                                 unsigned int* __restrict__ changed, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
     const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
 
     const unsigned int tid = threadIdx.x;
-    long long sb = s_begin + chunk0 * PI_BLOCK;
-    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+    long long sb = s_begin + chunk0 * PI_BLOCK_IMPROVE;
+    unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_IMPROVE) - 1));
     PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
-    pi_stage_table(tab, lds_tab);
+    pi_stage_table<PI_BLOCK_IMPROVE>(tab, lds_tab);
     __syncthreads();
 
     unsigned int n_changed = 0;
@@ -463,8 +484,8 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
         const long long sb_c = sb;
         const unsigned int lane_c = lane;
         if (k + 1 < n_here) {
-            sb += PI_BLOCK;
-            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK) - 1));
+            sb += PI_BLOCK_IMPROVE;
+            lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_IMPROVE) - 1));
             nxt = pi_load_state(V, policy, term, sb, lane);
         }
         const bool live = tid == lane_c;
@@ -490,11 +511,11 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
             pi_store_lane(Vn + sb_c, lane_c, cur.v_old);
         }
     }
-    if (changed != nullptr) pi_wave_sum_to(n_changed, changed);
-    if (WRITE_V && delta_bits != nullptr) pi_wave_max_to(dmax, delta_bits);
+    if (changed != nullptr) pi_wave_sum_to<PI_BLOCK_IMPROVE>(n_changed, changed);
+    if (WRITE_V && delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_IMPROVE>(dmax, delta_bits);
 }
 
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)
 pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
                         const unsigned char* __restrict__ term, const float* __restrict__ tab,
                         long long s_begin, long long s_end, float gamma,
@@ -502,7 +523,7 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
     pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed, cpw);
 }
 
-extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)
 pi_value_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn, int* __restrict__ policy,
                       const unsigned char* __restrict__ term, const float* __restrict__ tab,
                       long long s_begin, long long s_end, float gamma,
@@ -553,9 +574,9 @@ pi_reach_planes_kernel(const unsigned char* __restrict__ term, const float* __re
     __shared__ float lds_tab[PI_GRID.tab_len];
     __shared__ unsigned int lds_bits[PI_PLANE_WORDS];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
     const long long chunk_end = min(chunk0 + cpw, n_chunks);
-    pi_stage_table(tab, lds_tab);
+    pi_stage_table<PI_BLOCK>(tab, lds_tab);
     for (int i = threadIdx.x; i < PI_PLANE_WORDS; i += PI_BLOCK) lds_bits[i] = 0u;
     __syncthreads();
     unsigned int stride_dim = 1u, g_dim = 1u;
@@ -633,9 +654,9 @@ pi_probe_coords_kernel(const float* __restrict__ tab, long long s_begin, long lo
                        float* __restrict__ out, int cpw) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
     const long long chunk_end = min(chunk0 + cpw, n_chunks);
-    pi_stage_table(tab, lds_tab);
+    pi_stage_table<PI_BLOCK>(tab, lds_tab);
     __syncthreads();
     for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
         const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;

@@ -10,7 +10,9 @@ reference is imported or executed), pulls out
   * the ``_dynamics_cuda_src`` string of each runner's env class,
 
 writes both to a temporary directory and compiles oracle/ref_driver.cpp around them into
-``oracle/_ref/libref_<env>.so`` (git-ignored; no reference text is written into the repo).
+``$TMPDIR/pi_mi355_ref/libref_<env>.so`` — OUTSIDE the repository tree, so that neither reference
+text nor anything compiled from it can travel to the GPU box with a snapshot of the repo
+(tests/test_hygiene.py checks the tree).
 ``load(env)`` returns an ``oracle.OracleLib`` over that shared object, which
 tests/golden/make_golden.py uses to (a) pin oracle/pi_oracle.cpp + this repo's env strings
 bit-for-bit against the reference's text and (b) emit the golden vectors.
@@ -26,7 +28,7 @@ from . import OracleLib, CXX
 
 REFERENCE = Path("/root/reference")
 _HERE = Path(__file__).resolve().parent
-REF_DIR = _HERE / "_ref"
+REF_DIR = Path(tempfile.gettempdir()) / "pi_mi355_ref"
 
 # env name -> (runner file, class name, D)
 RUNNERS = {
@@ -80,7 +82,7 @@ def dynamics_text(env: str) -> str:
 
 def load(env: str, rebuild: bool = False) -> OracleLib:
     _, _, D = RUNNERS[env]
-    REF_DIR.mkdir(exist_ok=True)
+    REF_DIR.mkdir(parents=True, exist_ok=True)
     so = REF_DIR / f"libref_{env}.so"
     if rebuild or not so.exists():
         if not available():

@@ -1,16 +1,38 @@
 """
-runners/cartpole_cuda.py — train CartPole-v1 balance; reference runner runners/cartpole_cuda.py.
+runners/cartpole_cuda.py — train CartPole-v1 balance on (x, x_dot, theta, theta_dot); same entry point, flags and module-level names
+as the reference runner (runners/cartpole_cuda.py).
 
-    python runners/cartpole_cuda.py [--bins N] [--retrain] [--save-path results/cartpole_cuda_policy.npz]
+    python runners/cartpole_cuda.py [--bins N] [--retrain] [--save-path results/cartpole_cuda_policy.npz] [...]
 
-The env plugin (dynamics string, grid, actions, solver settings) is
-``dynamicprogramming_amd.envs.CartPoleCuda``; this script is only the entry point.
+Module surface kept from the reference runner: ``CartPoleCuda`` (the env plugin, defined in
+``dynamicprogramming_amd.envs``), ``BINS_PER_DIM``, ``BINS_SPACE``, ``ACTION_SPACE`` and
+``train(save_path)``.  The rollout / plot / render functions of the reference runner are not part
+of this package; their flags are accepted and ignored (runners/_cli.py).
 """
-from _cli import main, train  # noqa: F401  (runners/ is on sys.path when run as a script)
+from pathlib import Path
 
-from dynamicprogramming_amd.envs import CartPoleCuda  # noqa: E402,F401  re-exported for `from runners...`
+try:                      # imported as runners.<name>
+    from . import _cli
+except ImportError:       # run as a script: runners/ is on sys.path
+    import _cli
+
+from dynamicprogramming_amd.envs import CudaPIConfig, CartPoleCuda  # noqa: E402,F401
 
 ENV = "cartpole"
+DEFAULT_SAVE = "results/cartpole_cuda_policy.npz"
+BINS_PER_DIM = CartPoleCuda.DEFAULT_BINS
+BINS_SPACE = CartPoleCuda.bins_space(BINS_PER_DIM)
+ACTION_SPACE = CartPoleCuda.ACTIONS
+
+
+def train(save_path: Path = Path(DEFAULT_SAVE), **kw) -> CartPoleCuda:
+    """Policy iteration on BINS_SPACE x ACTION_SPACE with the runner's own solver settings, then
+    save (reference train(): config, construct, run(), save())."""
+    pi = CartPoleCuda(BINS_SPACE, ACTION_SPACE, CudaPIConfig(**CartPoleCuda.CONFIG), **kw)
+    pi.run()
+    pi.save(save_path)
+    return pi
+
 
 if __name__ == "__main__":
-    main(ENV, "results/cartpole_cuda_policy.npz")
+    _cli.main(ENV, DEFAULT_SAVE)

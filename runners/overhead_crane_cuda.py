@@ -1,16 +1,38 @@
 """
-runners/overhead_crane_cuda.py — train overhead crane anti-sway; reference runner runners/overhead_crane_cuda.py.
+runners/overhead_crane_cuda.py — train overhead crane positioning with sway damping; same entry point, flags and module-level names
+as the reference runner (runners/overhead_crane_cuda.py).
 
-    python runners/overhead_crane_cuda.py [--bins N] [--retrain] [--save-path results/overhead_crane_cuda_policy.npz]
+    python runners/overhead_crane_cuda.py [--bins N] [--retrain] [--save-path results/overhead_crane_cuda_policy.npz] [...]
 
-The env plugin (dynamics string, grid, actions, solver settings) is
-``dynamicprogramming_amd.envs.OverheadCraneCuda``; this script is only the entry point.
+Module surface kept from the reference runner: ``OverheadCraneCuda`` (the env plugin, defined in
+``dynamicprogramming_amd.envs``), ``BINS_PER_DIM``, ``BINS_SPACE``, ``ACTION_SPACE`` and
+``train(save_path)``.  The rollout / plot / render functions of the reference runner are not part
+of this package; their flags are accepted and ignored (runners/_cli.py).
 """
-from _cli import main, train  # noqa: F401  (runners/ is on sys.path when run as a script)
+from pathlib import Path
 
-from dynamicprogramming_amd.envs import OverheadCraneCuda  # noqa: E402,F401  re-exported for `from runners...`
+try:                      # imported as runners.<name>
+    from . import _cli
+except ImportError:       # run as a script: runners/ is on sys.path
+    import _cli
+
+from dynamicprogramming_amd.envs import CudaPIConfig, OverheadCraneCuda  # noqa: E402,F401
 
 ENV = "overhead_crane"
+DEFAULT_SAVE = "results/overhead_crane_cuda_policy.npz"
+BINS_PER_DIM = OverheadCraneCuda.DEFAULT_BINS
+BINS_SPACE = OverheadCraneCuda.bins_space(BINS_PER_DIM)
+ACTION_SPACE = OverheadCraneCuda.ACTIONS
+
+
+def train(save_path: Path = Path(DEFAULT_SAVE), **kw) -> OverheadCraneCuda:
+    """Policy iteration on BINS_SPACE x ACTION_SPACE with the runner's own solver settings, then
+    save (reference train(): config, construct, run(), save())."""
+    pi = OverheadCraneCuda(BINS_SPACE, ACTION_SPACE, CudaPIConfig(**OverheadCraneCuda.CONFIG), **kw)
+    pi.run()
+    pi.save(save_path)
+    return pi
+
 
 if __name__ == "__main__":
-    main(ENV, "results/overhead_crane_cuda_policy.npz")
+    _cli.main(ENV, DEFAULT_SAVE)

@@ -61,9 +61,8 @@ def bits_equal(a, b) -> bool:
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     if a.shape != b.shape:
         return False
-    if a.dtype == np.float32 and b.dtype == np.float32:
-        return bool(np.array_equal(a.view(np.uint32), b.view(np.uint32))
-                    or np.array_equal(a, b, equal_nan=True))
+    if a.dtype == np.float32 and b.dtype == np.float32:      # bit patterns: +0 != -0, NaN payloads count
+        return bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
     return bool(np.array_equal(a, b))
 
 

@@ -673,3 +673,40 @@ def test_full_size_c3_properties(cuda_device):
         assert np.array_equal(d_p2[a:b].cpu().numpy(), o_pol[a:b])
         assert int(d_changed.item()) == o_changed
     eng.close()
+
+
+def test_runner_script_end_to_end(cuda_device, tmp_path):
+    """`python runners/pendulum_cuda.py --bins 50 --retrain --save-path ...` (the reference's command
+    line, README.md:323-347) trains on the GPU and writes an archive with the reference's nine keys
+    and dtypes (src/cuda_policy_iteration.py:397-408); a second invocation without --retrain loads
+    it; the archive read with the raw key access of runners/hybrid_double_cartpole.py:35-43 drives
+    utils.get_optimal_action; V and policy equal the oracle's run."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from utils import get_optimal_action
+    root = Path(__file__).resolve().parents[1]
+    out = tmp_path / "sub" / "pendulum_policy"            # no suffix, missing parent: both fixed like the reference
+    cmd = [sys.executable, str(root / "runners" / "pendulum_cuda.py"), "--bins", "50", "--retrain",
+           "--save-path", str(out), "--episodes", "1", "--no-plot"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert res.returncode == 0, res.stdout + res.stderr
+    d = np.load(out.with_suffix(".npz"))
+    want = {"value_function": np.float32, "policy": np.int32, "bounds_low": np.float32,
+            "bounds_high": np.float32, "grid_shape": np.int32, "strides": np.int32, "corner_bits": np.int32,
+            "action_space": np.float32, "states_space": np.float32}
+    assert set(d.files) == set(want) and all(d[k].dtype == t for k, t in want.items())
+    assert d["states_space"].shape == (2500, 2) and d["corner_bits"].shape == (4, 2)
+    a = float(get_optimal_action(np.array([3.0, 0.0], np.float32), d["policy"], d["action_space"],
+                                 d["bounds_low"], d["bounds_high"], d["grid_shape"], d["strides"], d["corner_bits"]))
+    assert -2.0 <= a <= 2.0
+    cls = envs.ENVS["pendulum"]
+    bins = [np.asarray(b, np.float32) for b in cls.bins_space(50).values()]
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    ref = H.oracle_for("pendulum").run(oracle.states_from_bins(bins), cls.ACTIONS, np.zeros(2500, bool), lo, hi,
+                                       gshape, strides, **{k: v for k, v in cls.CONFIG.items() if k != "log_interval"})
+    H.assert_bits_equal(d["value_function"], ref["value_function"], "runner V vs oracle")
+    assert np.array_equal(d["policy"], ref["policy"])
+    res2 = subprocess.run(cmd[:2] + ["--save-path", str(out)], capture_output=True, text=True, timeout=300,
+                          cwd=tmp_path)
+    assert res2.returncode == 0 and "Loading existing policy" in res2.stdout

@@ -1,0 +1,49 @@
+"""Repository hygiene the grading contract depends on (task statement ③):
+the product never touches the oracle, and nothing derived from /root/reference sits in the tree
+that is snapshotted to the GPU box."""
+from __future__ import annotations
+
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+PRODUCT_DIRS = ["dynamicprogramming_amd", "src", "runners", "utils"]
+
+
+def _product_sources():
+    for d in PRODUCT_DIRS:
+        for p in (ROOT / d).rglob("*"):
+            if p.suffix in (".py", ".cpp", ".h", ".hip") and "__pycache__" not in p.parts:
+                yield p
+
+
+def test_product_code_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+tests\b|import\s+tests\b)", re.M)
+    offenders = [str(p.relative_to(ROOT)) for p in _product_sources() if p.suffix == ".py"
+                 and pat.search(p.read_text())]
+    assert not offenders, offenders
+    inc = re.compile(r"#\s*include\s*[\"<][^\">]*(oracle|ref_driver)", re.M)
+    native = [str(p.relative_to(ROOT)) for p in _product_sources() if p.suffix in (".cpp", ".h", ".hip")
+              and inc.search(p.read_text())]
+    assert not native, native
+
+
+def test_no_reference_derived_artifacts_in_the_tree():
+    """The reference-text checker (oracle/build_ref.py) is built under $TMPDIR; no shared object,
+    include file or cached text of it may exist under the repository root."""
+    assert not list(ROOT.rglob("libref_*.so")), "reference-derived shared objects in the tree"
+    ref_dir = ROOT / "oracle" / "_ref"
+    assert not ref_dir.exists() or not any(ref_dir.iterdir())
+    from oracle import build_ref
+    assert ROOT not in build_ref.REF_DIR.resolve().parents and build_ref.REF_DIR.resolve() != ROOT
+    # nothing in the tree reads /root/reference at run time except the fixture generator and its helper
+    allowed = {"oracle/build_ref.py", "tests/golden/make_golden.py", "tests/golden/make_barycentric_golden.py",
+               "tests/test_hygiene.py"}
+    offenders = []
+    for p in ROOT.rglob("*.py"):
+        rel = str(p.relative_to(ROOT))
+        if "__pycache__" in p.parts or rel.startswith(("gpurun_out/", ".")) or rel in allowed:
+            continue
+        if re.search(r"[\"']/root/reference", p.read_text()):
+            offenders.append(rel)
+    assert not offenders, offenders

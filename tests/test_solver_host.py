@@ -157,3 +157,72 @@ def test_value_iteration_and_checkpoint(tmp_path):
     H.assert_bits_equal(a.value_function, b.value_function, "resumed run")
     with pytest.raises(ValueError, match="different grid"):
         _solver(name, (20, 20), cfg).load_checkpoint(tmp_path / "ck")
+
+
+# ── runner command line (reference README.md:323-347) ───────────────────────
+REFERENCE_FLAGS = ["--render", "--record", "--random", "--episodes", "--steps", "--bins", "--seed",
+                   "--no-plot", "--retrain", "--save-path"]
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_runner_cli_accepts_the_reference_flag_set(name):
+    """Every flag of the reference's shared CLI parses with the reference's types and defaults;
+    the crane adds --start-x / --target-x (overhead_crane_cuda.py:588-591)."""
+    from runners import _cli
+    p = _cli.build_parser(name, f"results/{name}_cuda_policy.npz")
+    flags = {s for a in p._actions for s in a.option_strings}
+    assert set(REFERENCE_FLAGS) <= flags
+    d = p.parse_args([])
+    assert (d.render, d.random, d.record, d.episodes, d.steps, d.seed, d.no_plot, d.retrain) == (
+        False, None, None, 5, 1000, 42, False, False)
+    assert d.bins == envs.ENVS[name].DEFAULT_BINS and str(d.save_path) == f"results/{name}_cuda_policy.npz"
+    a = p.parse_args(["--render", "--record", "out.gif", "--random", "--episodes", "3", "--steps", "10",
+                      "--bins", "12", "--seed", "7", "--no-plot", "--retrain", "--save-path", "x/y.npz"])
+    assert a.random == 5 and a.bins == 12 and a.retrain and str(a.record) == "out.gif"
+    assert p.parse_args(["--random", "9"]).random == 9
+    if name == "overhead_crane":
+        c = p.parse_args(["--target-x", "0.0", "--start-x", "1.5"])
+        assert (c.target_x, c.start_x) == (0.0, 1.5) and p.parse_args([]).target_x == -2.5
+    else:
+        assert "--target-x" not in flags
+
+
+def test_runner_modules_keep_the_reference_module_surface():
+    import importlib
+    for name, cls in envs.ENVS.items():
+        mod = importlib.import_module(f"runners.{name}_cuda")
+        assert getattr(mod, cls.__name__) is cls
+        assert mod.BINS_PER_DIM == cls.DEFAULT_BINS and list(mod.BINS_SPACE) == list(cls.bins_space(2))
+        assert np.array_equal(mod.ACTION_SPACE, cls.ACTIONS) and callable(mod.train)
+
+
+def test_runner_loads_an_existing_archive_without_a_gpu(tmp_path, capsys):
+    """No --retrain and the archive exists -> load() (works without GPU or library), exactly the
+    reference's control flow; the archive here has the reference's exact key set and dtypes
+    (runners/results/mountain_car_cuda_policy.npz), rebuilt around the reference-produced V / policy
+    of tests/golden/reference_results.npz, and is then read back the way
+    runners/hybrid_double_cartpole.py:35-43 reads it (raw keys) and fed to utils.get_optimal_action."""
+    from itertools import product
+    from runners import _cli
+    from utils import get_optimal_action
+    g = H.golden("reference_results")
+    shape = tuple(int(x) for x in g["mountain_car_grid_shape"])
+    bins = H.env_bins("mountain_car", shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    path = tmp_path / "mc_policy.npz"
+    np.savez(path, value_function=g["mountain_car_value_function"], policy=g["mountain_car_policy"],
+             bounds_low=lo, bounds_high=hi, grid_shape=gshape, strides=strides,
+             corner_bits=np.array(list(product([0, 1], repeat=2)), dtype=np.int32),
+             action_space=g["mountain_car_action_space"], states_space=oracle.states_from_bins(bins))
+    pi = _cli.main("mountain_car", "unused.npz", ["--save-path", str(path), "--episodes", "2", "--no-plot"])
+    assert "accepted and ignored" in capsys.readouterr().out
+    assert type(pi).__name__ == "MountainCarCuda" and pi.n_states == 40000 and pi.n_actions == 3
+    for key in ("value_function", "policy", "bounds_low", "bounds_high", "grid_shape", "strides",
+                "corner_bits", "action_space", "states_space"):
+        assert np.array_equal(getattr(pi, key), np.load(path)[key]), key
+    d = np.load(path)                                   # the hybrid runner's raw access
+    a = float(get_optimal_action(np.array([-0.5, 0.0], np.float32), d["policy"], d["action_space"],
+                                 d["bounds_low"], d["bounds_high"], d["grid_shape"], d["strides"],
+                                 d["corner_bits"]))
+    assert d["action_space"].min() <= a <= d["action_space"].max()
+    assert _cli.main("mountain_car", "unused.npz", ["--random"]) is None      # no training, like the reference

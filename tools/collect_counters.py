@@ -14,15 +14,9 @@ LAST = int(os.environ.get("PI_LAST", "20"))
 
 
 def head_hash():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import hashlib
-    h = hashlib.sha256()
-    for rel in ("dynamicprogramming_amd/csrc/pi_sweep_kernels.hip", "include/pi_math.h",
-                "dynamicprogramming_amd/csrc/pi_api.cpp"):
-        p = os.path.join(root, rel)
-        if os.path.exists(p):
-            h.update(open(p, "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dynamicprogramming_amd import _native
+    return _native.kernel_source_hash()
 
 
 def passes(label):
