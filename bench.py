@@ -105,15 +105,40 @@ def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict
         dt = time.perf_counter() - t0
         return len(flat) * (EVAL_PER_STEP + IMPROVE_PER_STEP * len(cls.ACTIONS)) / dt, dt, stride
 
-    many, dt_many, stride_many = run(sample_states, all_threads)
-    one, dt_one, stride_one = run(max(sample_states // 8, 1), 1)
+    m_all = min(sample_states, n)
+    many, dt_many, stride_many = run(m_all, all_threads)
+    one, dt_one, stride_one = run(max(m_all // 16, 1), 1)
     chk.set_threads(all_threads)
     return {"value": many, "unit": "backups/s", "cores": all_threads, "kind": "port",
             "value_1_thread": one, "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+            "numpy_reference_c1": numpy_reference_c1(),
             "sample": f"one step (10 eval + 1 improve sweeps) over every {stride_many}-th state of the same "
-                      f"{bins}^{cls._D} grid ({sample_states} states, {dt_many:.1f} s wall, "
+                      f"{bins}^{cls._D} grid ({m_all} states, {dt_many:.1f} s wall, "
                       f"oracle/pi_oracle.cpp with OpenMP, {all_threads} threads); 1 thread: every "
                       f"{stride_one}-th state, {dt_one:.1f} s wall"}
+
+
+def numpy_reference_c1() -> dict:
+    """BASELINE config 1: the vectorised numpy sweep (oracle/numpy_reference.py) on Pendulum 50 x 50 x 11."""
+    from oracle import numpy_reference as NR
+    from dynamicprogramming_amd import envs
+    cls = envs.ENVS["pendulum"]
+    ref = NR.PendulumNumpy([np.asarray(b, np.float32) for b in cls.bins_space(50).values()],
+                           np.linspace(-2.0, 2.0, 11, dtype=np.float32))
+    ref.gamma = np.float32(0.99)
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal(ref.n).astype(np.float32)
+    pol = rng.integers(0, 11, ref.n).astype(np.int32)
+    ref.eval_sweep(V, pol)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for _ in range(EVAL_PER_STEP):
+            ref.eval_sweep(V, pol)
+        ref.improve_sweep(V, pol)
+    dt = time.perf_counter() - t0
+    return {"value": reps * ref.n * (EVAL_PER_STEP + 11) / dt, "unit": "backups/s", "cores": 1,
+            "config": "Pendulum 50 x 50 x 11 actions, numpy float32, one thread"}
 
 
 def load_profile(n_states: int, kernel_hash: str):
@@ -140,8 +165,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converged-state", action="store_true",
                     help="skip the policy-iteration-state measurement (3 outer iterations, ~4 s)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 23,
-                    help="states of the same grid the all-core CPU baseline sweeps (about 15 CPU-seconds)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 26,
+                    help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
+                         "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
+                         "the 1-thread run takes every 16th of those)")
     args = ap.parse_args()
 
     import torch

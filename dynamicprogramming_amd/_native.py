@@ -74,12 +74,11 @@ class NativeError(RuntimeError):
 
 
 def kernel_source_hash() -> str:
-    """Fingerprint of the device code and its host driver: profiles record it so that counters
-    measured on one version of the kernels are never quoted for another (bench.py)."""
+    """Fingerprint of the device code (kernel template + math header): profiles record it so that
+    counters measured on one version of the kernels are never quoted for another (bench.py)."""
     import hashlib
     h = hashlib.sha256()
-    for path in (_PKG / "csrc" / "pi_sweep_kernels.hip", _PKG.parent / "include" / "pi_math.h",
-                 _PKG / "csrc" / "pi_api.cpp"):
+    for path in (_PKG / "csrc" / "pi_sweep_kernels.hip", _PKG.parent / "include" / "pi_math.h"):
         h.update(path.read_bytes())
     return h.hexdigest()[:16]
 

@@ -137,7 +137,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         device       : torch device of this rank (default: current CUDA device)
         process_group: torch.distributed group to shard over (default: WORLD if initialised)
         transport    : multi-rank transport (transport.py); default: the library's RCCL transport,
-                       bootstrapped over `process_group`, when torch.distributed is initialised
+                       bootstrapped over `process_group`, when torch.distributed is initialised;
+                       False = stay single-rank even then
         backend_factory : sweep-backend constructor; tests inject a CPU checker here, the
                        product default is the HIP backend and is never replaced silently.
         """
@@ -267,7 +268,9 @@ class _CudaPolicyIterationBase(abc.ABC):
         """Pick the transport (None on a single rank) and this rank's contiguous state shard."""
         from . import transport as T
         comm = self._transport_arg
-        if comm is None:
+        if comm is False:                               # explicit single-rank solver
+            comm = None
+        elif comm is None:
             try:
                 import torch.distributed as dist
                 active = dist.is_available() and dist.is_initialized()

@@ -710,3 +710,47 @@ def test_runner_script_end_to_end(cuda_device, tmp_path):
     res2 = subprocess.run(cmd[:2] + ["--save-path", str(out)], capture_output=True, text=True, timeout=300,
                           cwd=tmp_path)
     assert res2.returncode == 0 and "Loading existing policy" in res2.stdout
+
+
+def test_rccl_entry_points_world_1(cuda_device):
+    """The RCCL side of the C ABI with a one-rank communicator (all a single-GPU box can host):
+    pi_comm_unique_id / pi_comm_init, in-place all-gathers, scalar all-reduces, pi_exchange_plan and
+    the sharded sweep drivers must reproduce the unsharded entry points bit for bit."""
+    torch = _torch()
+    name, shape = "double_pendulum_swingup", (12, 9, 11, 10)
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, seed=9)
+    n = len(states)
+    gamma = float(np.float32(0.999))
+    uid = _native.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(0, 1, uid)
+    assert (eng.comm_info(0), eng.comm_info(1), eng.comm_info(2)) == (0, 1, 1)
+    d_pol, d_term = _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
+    info = eng.exchange_plan(d_term.data_ptr(), n, 0, True)
+    assert info["recv_elems"] == 0 and eng.comm_info(3) in (1, 2)
+    A, B = _dev(V, cuda_device), torch.zeros(n, dtype=torch.float32, device=cuda_device)
+    A2, B2 = A.clone(), B.clone()
+    d1 = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    d2 = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweeps_sharded(A.data_ptr(), B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), gamma, 7, d1.data_ptr())
+    eng.eval_sweeps(A2.data_ptr(), B2.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 7, d2.data_ptr())
+    assert torch.equal(A, A2) and torch.equal(B, B2) and float(d1.item()) == float(d2.item())
+    c1 = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    c2 = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    p1, p2 = d_pol.clone(), d_pol.clone()
+    eng.improve_sweep_sharded(B.data_ptr(), p1.data_ptr(), d_term.data_ptr(), gamma, c1.data_ptr())
+    eng.improve_sweep(B2.data_ptr(), p2.data_ptr(), d_term.data_ptr(), 0, n, gamma, c2.data_ptr())
+    assert torch.equal(p1, p2) and int(c1.item()) == int(c2.item())
+    before = B.clone()
+    eng.allgather_V(B.data_ptr(), n)
+    eng.allgather_policy(p1.data_ptr(), n)
+    eng.exchange_V(B.data_ptr())
+    eng.allreduce_max_f32(d1.data_ptr())
+    eng.allreduce_sum_u32(c1.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(B, before) and torch.equal(p1, p2)
+    assert float(d1.item()) == float(d2.item()) and int(c1.item()) == int(c2.item())
+    eng.comm_destroy()
+    with pytest.raises(_native.NativeError, match="no communicator"):
+        eng.allgather_V(B.data_ptr(), n)
+    eng.close()

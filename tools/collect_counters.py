@@ -42,10 +42,33 @@ def passes(label):
     return counters, durations
 
 
+def measured_valu_peak():
+    """Best chip-wide wave-instruction rate of tools/valu_issue_bench.hip (same output directory tree)."""
+    best = None
+    for cand in glob.glob(os.path.join(os.path.dirname(out.rstrip("/")), "valu_issue.txt")) + \
+            glob.glob(os.path.join(out, "valu_issue.txt")):
+        for line in open(cand):
+            f = line.split()
+            if line.startswith("#") or len(f) < 6:
+                continue
+            try:
+                g = float(f[-2])
+            except ValueError:
+                continue
+            if f[0].startswith("v_") and (best is None or g > best):
+                best = g
+    return best
+
+
+# cycles per wave64 instruction per SIMD at saturation (profiles/r02/valu_issue.txt): fp32
+# fma/mul/add class, everything else, transcendentals
+COST_A, COST_B, COST_C = 2.3, 4.15, 8.15
 cal = None
 for label in labels:
     counters, durations = passes(label)
-    res = {"label": label, "kernel_source_hash": head_hash(), "dispatches_averaged": LAST, "kernels": {}}
+    res = {"label": label, "kernel_source_hash": head_hash(), "dispatches_averaged": LAST,
+           "states": int(os.environ.get("PI_STATES", str(80 ** 4))),
+           "valu_peak_measured_Ginst_per_s": measured_valu_peak(), "kernels": {}}
     for k in sorted(counters):
         c = {name: sum(v) / len(v) for name, v in counters[k].items() if v}
         e = {"counters": c}
@@ -61,6 +84,16 @@ for label in labels:
                 e["vmem_rd_insts_per_wave"] = c["SQ_INSTS_VMEM_RD"] / w
             if "SQ_WAVE_CYCLES" in c:
                 e["wave_cycles_per_wave_x4"] = 4 * c["SQ_WAVE_CYCLES"] / w
+            if all(k in c for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
+                                    "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32")):
+                a = (c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / w
+                t = c["SQ_INSTS_VALU_TRANS_F32"] / w
+                b = c["SQ_INSTS_VALU"] / w - a - t
+                e["issue_cycles_model"] = {
+                    "fp32_fma_mul_add_per_wave": a, "transcendental_per_wave": t, "other_valu_per_wave": b,
+                    "cycles_per_inst": [COST_A, COST_B, COST_C],
+                    "simd_cycles_per_wave": a * COST_A + b * COST_B + t * COST_C,
+                    "note": "integer adds / and / xor issue at the fp32 rate but are counted as 'other': an upper estimate"}
         if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
             for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                          "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):

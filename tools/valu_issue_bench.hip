@@ -138,6 +138,15 @@ DEFINE_BENCH(bench_mix_fma_max, float,
              PI_I(2, "v_fma_f32 ", ", %8, %9, ", "") PI_I(3, "v_max_f32 ", ", %8, ", "")
              PI_I(4, "v_fma_f32 ", ", %8, %9, ", "") PI_I(5, "v_max_f32 ", ", %8, ", "")
              PI_I(6, "v_fma_f32 ", ", %8, %9, ", "") PI_I(7, "v_max_f32 ", ", %8, ", ""))
+// v_cndmask reading a condition that a v_cmp of the same wave has just produced (the realistic use;
+// the bare v_cndmask_b32 row above reads a VCC that no instruction of the loop ever writes and is
+// an outlier at ~23 cycles): two instructions per accumulator, so divide the pair's cost by two.
+#define PI_CS(k) "v_cmp_gt_f32 vcc, %" #k ", %8\n\tv_cndmask_b32 %" #k ", %8, %" #k ", vcc\n\t"
+DEFINE_BENCH(bench_pair_cmp_cndmask, float,
+             PI_CS(0) PI_CS(1) PI_CS(2) PI_CS(3))
+#define PI_CS64(k) "v_cmp_gt_f32 s[40:41], %" #k ", %8\n\tv_cndmask_b32 %" #k ", %8, %" #k ", s[40:41]\n\t"
+DEFINE_BENCH(bench_pair_cmp_cndmask_sgpr, float,
+             PI_CS64(0) PI_CS64(1) PI_CS64(2) PI_CS64(3))
 DEFINE_BENCH(bench_mix_fma_snop, float,
              PI_I(0, "v_fma_f32 ", ", %8, %9, ", "") "s_nop 0\n\t"
              PI_I(2, "v_fma_f32 ", ", %8, %9, ", "") "s_nop 0\n\t"
@@ -164,7 +173,9 @@ int main(int argc, char** argv) {
                         {"v_mul_f32 dependent chain", bench_dep_v_mul_f32},
                         {"v_max_f32 dependent chain", bench_dep_v_max_f32},
                         {"mix fma,max alternating", bench_mix_fma_max},
-                        {"mix fma,s_nop alternating", bench_mix_fma_snop}};
+                        {"mix fma,s_nop alternating", bench_mix_fma_snop},
+                        {"pair v_cmp+v_cndmask (vcc)", bench_pair_cmp_cndmask},
+                        {"pair v_cmp+v_cndmask (sgpr)", bench_pair_cmp_cndmask_sgpr}};
     float* sink;
     CHECK(hipMalloc((void**)&sink, 4));
     hipEvent_t e0, e1;
