@@ -17,7 +17,8 @@ import torch.distributed as dist
 from dynamicprogramming_amd import envs
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+# PI_SMOKE_ONE_GPU=1: every rank on device 0 (rehearsal on a one-GPU box, if RCCL accepts it)
+torch.cuda.set_device(0 if os.environ.get("PI_SMOKE_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0)))
 dev = torch.device("cuda", torch.cuda.current_device())
 dist.init_process_group("nccl", device_id=dev)
 cls = envs.ENVS["pendulum"]
