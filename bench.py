@@ -363,8 +363,13 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        # tear down in a defined order: drain the GPU, let every rank arrive, destroy the library's
+        # RCCL communicator (it dies with the engine handle), then torch's process group
+        torch.cuda.synchronize()
+        dist.barrier()
+        solver._backend.close()
         dist.destroy_process_group()
 
 

@@ -153,3 +153,64 @@ def test_missing_library_raises(monkeypatch, tmp_path):
 
 def test_ctypes_pointer_sizes():
     assert ctypes.sizeof(ctypes.c_void_p) == 8
+
+
+# ── the interpolation's division through a proven reciprocal ───────────
+def _markstein_f32(a, span):
+    """The kernels' sequence t = a*y; r = fma(-t, span, a); q = fma(r, y, t), in numpy.  float64 holds
+    every float32 product exactly and the sums here to far more than float32 precision, so rounding
+    the float64 expression once to float32 reproduces the fused operation."""
+    f32, f64 = np.float32, np.float64
+    y = f32(1.0) / f32(span)
+    t = (a * y).astype(f32)
+    r = (a.astype(f64) - t.astype(f64) * f64(span)).astype(f32)           # fma(-t, span, a)
+    return (r.astype(f64) * f64(y) + t.astype(f64)).astype(f32)            # fma(r, y, t)
+
+
+@pytest.mark.parametrize("name", H.ENV_NAMES)
+def test_reciprocal_division_is_enabled_and_exact_for_every_env_divisor(name, monkeypatch):
+    """pi_create proves the reciprocal-multiply division per divisor by enumerating all 2^23
+    significands (C++); this checks the verdict independently: the reference grids' divisors are
+    accepted (pi_info 20 + d), PI_MI355_IEEE_DIV switches the path off, the generated source carries
+    the span and its reciprocal as exact hex-float literals, and a numpy restatement of the sequence
+    equals IEEE division on a million dividends spread over the guarded exponent range."""
+    cls = envs.ENVS[name]
+    bins = [np.asarray(b, np.float32) for b in cls.bins_space(cls.DEFAULT_BINS).values()]
+    eng = _native.Engine(cls._D, [len(b) for b in bins], [b.min() for b in bins], [b.max() for b in bins],
+                         bins, cls.ACTIONS, device=-1)
+    assert [eng.info(20 + d) for d in range(cls._D)] == [1] * cls._D
+    src = eng.kernel_source(envs.dynamics_source(name))
+
+    def literals(macro):
+        body = re.search(rf"#define {macro} \{{(.*?)\}}", src).group(1)
+        return [np.float32(float.fromhex(tok.strip().rstrip("f"))) for tok in body.split(",")]
+
+    spans, rcps, los = literals("PI_SPAN_INIT"), literals("PI_RCP_INIT"), literals("PI_LO_INIT")
+    rng = np.random.default_rng(11)
+    for d, b in enumerate(bins):
+        span = np.float32(b.max()) - np.float32(b.min())
+        assert spans[d] == span and rcps[d] == np.float32(1.0) / span and los[d] == np.float32(b.min())
+        mant = rng.integers(0, 1 << 23, 1_000_000, dtype=np.uint64).astype(np.uint32)
+        expo = rng.integers(127 - 38, 127 + 38, 1_000_000, dtype=np.uint64).astype(np.uint32)
+        sign = rng.integers(0, 2, 1_000_000, dtype=np.uint64).astype(np.uint32) << np.uint32(31)
+        a = (sign | (expo << np.uint32(23)) | mant).view(np.float32)
+        want = (a / span).astype(np.float32)
+        got = _markstein_f32(a, span)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"dimension {d}, span {span!r}"
+    eng.close()
+    monkeypatch.setenv("PI_MI355_IEEE_DIV", "1")
+    off = _native.Engine(cls._D, [len(b) for b in bins], [b.min() for b in bins], [b.max() for b in bins],
+                         bins, cls.ACTIONS, device=-1)
+    assert [off.info(20 + d) for d in range(cls._D)] == [0] * cls._D
+    assert "PI_FASTDIV_INIT {" + ",".join(["0"] * cls._D) + "}" in off.kernel_source(envs.dynamics_source(name))
+    off.close()
+
+
+def test_reciprocal_division_refuses_out_of_range_divisors():
+    """Spans outside [2^-30, 2^30] (where an intermediate could leave the normal range) keep the
+    IEEE division for that dimension only."""
+    bins = [np.linspace(0, 1e-12, 5, dtype=np.float32), np.linspace(-1.0, 1.0, 7, dtype=np.float32)]
+    eng = _native.Engine(2, [5, 7], [b.min() for b in bins], [b.max() for b in bins], bins,
+                         np.array([0.0], np.float32), device=-1)
+    assert [eng.info(20), eng.info(21)] == [0, 1]
+    eng.close()
