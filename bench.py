@@ -19,12 +19,17 @@ csrc/pi_comm.cpp); torch.distributed only hands the RCCL id around and times the
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
   roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a gather/reduce with
                   ~400 fp32 VALU instructions of dynamics per state; they are bound by VALU ISSUE
-                  and by the vector L1's line throughput, not by HBM.  So:
-                  achieved = VALU wave-instructions per second = (instructions per wave, from the
-                  committed PMC profile of THIS kernel version) x waves per launch / mean launch
-                  time (HIP events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2
-                  cycles per wave64 fp32 instruction (MI355X_MICROARCH.md) = 1228.8 G/s; the
-                  best measured rate (tools/valu_issue_bench.hip) is given as peak_measured.
+                  and by the vector L1's line throughput, not by HBM.  So the
+                  bound is the SIMD issue time of the kernel's own instruction mix:
+                  achieved = SIMD issue-cycles delivered per second = (instructions per wave by
+                  class, from the committed PMC profile of THIS kernel version) x (cycles per wave64
+                  instruction of that class, measured by tools/valu_issue_bench.hip: 2.3 fp32
+                  fma/mul/add, 4.15 other, 8.15 transcendental) x waves per launch / mean launch time
+                  (HIP events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz = 2457.6 G
+                  SIMD-cycles/s (MI355X_MICROARCH.md clock); frac = achieved / peak, i.e. the time
+                  the instruction mix needs at the NOMINAL clock over the time the launch took (the
+                  chip holds ~2.0-2.1 GHz under this load: clock_GHz_under_profiler).  The plain
+                  instruction rate is given too (valu_Ginst_per_s).
                   traffic = HBM-side bytes per launch from the same profile (FETCH_SIZE x 2 on
                   gfx950 + WRITE_SIZE), withheld when the profile is of another kernel version.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
@@ -53,6 +58,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0     # wave64 fp32 VALU instructions/s: 2 cycles each per SIMD-32
+SIMD_PEAK_GCYC = 256 * 4 * 2.4           # SIMD issue-cycles per second at the nominal 2.4 GHz
 ENV = "double_pendulum_swingup"
 BINS = 80
 EVAL_PER_STEP = 10
@@ -165,6 +171,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converged-state", action="store_true",
                     help="skip the policy-iteration-state measurement (3 outer iterations, ~4 s)")
+    ap.add_argument("--full-run", action="store_true",
+                    help="also run policy iteration to convergence from V = 0 (the metric's 'sweeps-to-converge' "
+                         "part; ~45 s on C4) and report sweeps, outer iterations and wall time")
     ap.add_argument("--cpu-sample", type=int, default=1 << 26,
                     help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
                          "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
@@ -269,6 +278,21 @@ def main() -> None:
                      "policy = 0 with at most 2000 evaluation sweeps each", "prepare_seconds": t_prep,
                      "residual": float(solver._d_delta.item())}
 
+    # ── sweeps-to-converge (optional: a full run() from V = 0 with the env's own settings) ───
+    full_run = None
+    if args.full_run:
+        fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
+        torch.cuda.synchronize()
+        t_run = time.perf_counter()
+        fresh.run()
+        t_run = time.perf_counter() - t_run
+        st = fresh.stats
+        full_run = {"pi_iterations": st["pi_iterations"], "eval_sweeps": st["eval_sweeps"],
+                    "improve_sweeps": st["improve_sweeps"], "stable": st.get("stable"), "seconds": t_run,
+                    "backups_per_s": n * (st["eval_sweeps"] + st["improve_sweeps"] * nA) / t_run,
+                    "us_per_eval_sweep": t_run / max(st["eval_sweeps"], 1) * 1e6}
+        del fresh
+
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
     prof, prof_path = load_profile(n, khash) if (world == 1 and args.env == ENV and args.bins == BINS) else (None, None)
@@ -288,8 +312,18 @@ def main() -> None:
             insts = k["valu_insts_per_wave"] * waves
             ach = insts / (ms * 1e-3) / 1e9
             e["valu"] = {"insts_per_wave": k["valu_insts_per_wave"], "waves_per_launch": waves,
-                         "achieved_Ginst_per_s": ach, "frac_of_peak": ach / VALU_PEAK_GIPS,
+                         "achieved_Ginst_per_s": ach, "inst_rate_frac_of_peak": ach / VALU_PEAK_GIPS,
                          "issue_cycles_model": k.get("issue_cycles_model")}
+            model = k.get("issue_cycles_model")
+            if model:
+                cyc = model["simd_cycles_per_wave"] * waves            # SIMD issue-cycles per launch
+                e["valu"]["achieved_Gcyc_per_s"] = cyc / (ms * 1e-3) / 1e9
+                e["valu"]["issue_frac"] = e["valu"]["achieved_Gcyc_per_s"] / SIMD_PEAK_GCYC
+                gui = k["counters"].get("GRBM_GUI_ACTIVE")
+                prof_ms = k.get("ms_under_profiler")
+                if gui and prof_ms:
+                    clock_ghz = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # sum over the 8 XCDs
+                    e["valu"]["clock_GHz_under_profiler"] = clock_ghz
             if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
                 e["hbm_traffic_bytes"] = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
                 e["l2_hit_rate"] = k.get("l2_hit_rate")
@@ -303,16 +337,22 @@ def main() -> None:
         kernels["eval_converged_policy"] = converged
     share = {"eval_sweeps": eval_ms * EVAL_PER_STEP, "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dom = kernels["eval_sweep"] if share["eval_sweeps"] >= share["improve_sweep"] else kernels["improve_sweep"]
-    roofline = {"bound": "valu-issue", "kernel": dom["kernel"], "achieved": None, "peak": VALU_PEAK_GIPS,
-                "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+    roofline = {"bound": "valu-issue", "kernel": dom["kernel"], "achieved": None, "peak": SIMD_PEAK_GCYC,
+                "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
                 "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash, "profile": prof_path,
-                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 fp32 instruction",
-                "peak_measured": (prof or {}).get("valu_peak_measured_Ginst_per_s")}
-    if "valu" in dom:
-        roofline["achieved"] = dom["valu"]["achieved_Ginst_per_s"]
-        roofline["frac"] = dom["valu"]["frac_of_peak"]
-        roofline["insts_per_wave"] = dom["valu"]["insts_per_wave"]
-        roofline["waves_per_launch"] = dom["valu"]["waves_per_launch"]
+                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
+                "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
+    if "valu" in dom and "issue_frac" in dom["valu"]:
+        v = dom["valu"]
+        roofline["achieved"] = v["achieved_Gcyc_per_s"]
+        roofline["frac"] = v["issue_frac"]
+        roofline["clock_GHz_under_profiler"] = v.get("clock_GHz_under_profiler")
+        roofline["insts_per_wave"] = v["insts_per_wave"]
+        roofline["waves_per_launch"] = v["waves_per_launch"]
+        roofline["issue_cycles_model"] = v["issue_cycles_model"]
+        roofline["valu_Ginst_per_s"] = v["achieved_Ginst_per_s"]
+        roofline["valu_inst_rate_peak_Ginst_per_s"] = VALU_PEAK_GIPS
+        roofline["valu_inst_rate_measured_peak_Ginst_per_s"] = (prof or {}).get("valu_peak_measured_Ginst_per_s")
     if "hbm_traffic_bytes" in dom:
         roofline["traffic"] = dom["hbm_traffic_bytes"]
         roofline["traffic_vs_compulsory"] = dom["hbm_traffic_bytes"] / compulsory
@@ -351,6 +391,7 @@ def main() -> None:
         "roofline_algorithmic": roofline_algorithmic,
         "kernels": kernels,
         "time_share_ms": share,
+        "sweeps_to_converge": full_run,
         "eval_backups_per_s": states_per_launch * world / (eval_ms * 1e-3),
         "improve_backups_per_s": states_per_launch * world * nA / (improve_ms * 1e-3),
         "check": {"last_residual": last_delta, "last_changed": last_changed,
