@@ -32,10 +32,40 @@ def coords_of(flat):
     return np.stack([tables[d][idx[:, d]] for d in range(D)], axis=1).astype(np.float32), idx
 
 
+def fit_shear():
+    """Least-squares slope of (successor cell - own index) in every dimension against the index of
+    the last (lane) dimension, over random states and actions: theta' = theta + dt * omega makes the
+    successor's theta_2 row drift linearly along a wave's omega_2 lanes."""
+    m = 100000
+    flat = rng.choice(n, size=m, replace=False)
+    st, idx = coords_of(flat)
+    ns, _, _ = chk.step(st, rng.choice(cls.ACTIONS, size=m).astype(np.float32))
+    beta = np.zeros(D)
+    for d in range(D - 1):
+        dc = (ns[:, d] - lo[d]) / (hi[d] - lo[d]) * (shape[d] - 1) - idx[:, d]
+        ok = np.abs(dc) < shape[d] / 3                       # drop wrapped angles
+        A = np.stack([idx[ok, D - 1], np.ones(ok.sum())], axis=1)
+        beta[d] = np.linalg.lstsq(A, dc[ok], rcond=None)[0][0]
+    return beta
+
+
+_shear = None
+
+
 def wave_states(mapping, w):
     """flat indices of the 64 lanes of sampled wave number w under a mapping."""
     if mapping == "flat":                       # lanes = consecutive flat indices (current kernel)
         return w * 64 + np.arange(64)
+    if mapping == "shear":                      # lanes follow the drift: i_d = (r_d - round(beta_d * i_last)) mod g_d
+        global _shear
+        if _shear is None:
+            beta = fit_shear()
+            print("shear slopes (cells per lane index):", np.round(beta, 4), flush=True)
+            _shear = [np.rint(beta[d] * (np.arange(shape[-1]) - shape[-1] // 2)).astype(int) for d in range(D)]
+        pi = np.stack(np.unravel_index((w * 64 + np.arange(64)) % n, tuple(shape)), axis=1)
+        for d in range(D - 1):
+            pi[:, d] = (pi[:, d] - _shear[d][pi[:, D - 1]]) % shape[d]
+        return np.ravel_multi_index(tuple(pi.T), tuple(shape))
     if mapping.startswith("tile"):              # lanes = t2 x t3 tile of the last two dimensions
         t2, t3 = map(int, mapping[4:].split("x"))
         g2, g3 = shape[-2], shape[-1]
@@ -80,7 +110,7 @@ def analyse(mapping, action_mode, n_waves=4000):
     return lp.mean(), np.percentile(lp, [10, 50, 90]), np.mean(cells)
 
 
-for mapping in ["flat", "tile8x8", "tile4x16", "tile2x32", "tile16x4"]:
+for mapping in ["flat", "shear", "tile8x8", "tile4x16", "tile2x32", "tile16x4"]:
     for mode in ["bang", "random", "0.0"]:
         m, pct, cells = analyse(mapping, mode, 1500)
         print(f"{env}@{bins} mapping={mapping:9s} action={mode:6s}: lines per corner-pair load mean {m:5.1f} "
