@@ -17,19 +17,23 @@ inside libpi_mi355.so over RCCL (halo exchange of the reachable planes, or an al
 csrc/pi_comm.cpp); torch.distributed only hands the RCCL id around and times the run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
-  roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a gather/reduce with
-                  ~400 fp32 VALU instructions of dynamics per state; they are bound by VALU ISSUE
-                  and by the vector L1's line throughput, not by HBM.  So the
-                  bound is the SIMD issue time of the kernel's own instruction mix:
-                  achieved = SIMD issue-cycles delivered per second = (instructions per wave by
-                  class, from the committed PMC profile of THIS kernel version) x (cycles per wave64
-                  instruction of that class, measured by tools/valu_issue_bench.hip: 2.3 fp32
-                  fma/mul/add, 4.15 other, 8.15 transcendental) x waves per launch / mean launch time
-                  (HIP events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz = 2457.6 G
-                  SIMD-cycles/s (MI355X_MICROARCH.md clock); frac = achieved / peak, i.e. the time
-                  the instruction mix needs at the NOMINAL clock over the time the launch took (the
-                  chip holds ~2.0-2.1 GHz under this load: clock_GHz_under_profiler).  The plain
-                  instruction rate is given too (valu_Ginst_per_s).
+  roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a divergent gather plus
+                  ~400 fp32 VALU instructions of dynamics per state; HBM is not what bounds them
+                  (27 % of 8 TB/s).  Two on-chip bounds are computed from the committed PMC profile of
+                  THIS kernel version and the launch time measured here (HIP events on the launch
+                  stream), and `roofline` is the one with the larger fraction (`bounds` has both):
+                    l1-gather  : cycles of the CU's vector L1 (TCP) = TCP_TOTAL_CACHE_ACCESSES (one
+                                 per distinct 128-B line of a wave-wide load, at least 16 per 8-byte
+                                 load) + 1.23 x TCP->TCC requests (lines that L2 serves), as measured by
+                                 tools/tcp_gather_bench.hip (profiles/r02/tcp_gather.txt);
+                                 peak = 256 CUs x 2.4 GHz = 614.4 G TCP-cycles/s;
+                    valu-issue : SIMD issue-cycles of the instruction mix = instructions per wave by
+                                 class x cycles per wave64 instruction of that class
+                                 (tools/valu_issue_bench.hip: 2.3 fp32 fma/mul/add, 4.15 other, 8.15
+                                 transcendental) x waves; peak = 256 CUs x 4 SIMDs x 2.4 GHz.
+                  frac = achieved / peak = the time the kernel needs on that unit at the NOMINAL clock
+                  over the time the launch took (the chip holds ~2.0-2.1 GHz under this load:
+                  clock_GHz_under_profiler).
                   traffic = HBM-side bytes per launch from the same profile (FETCH_SIZE x 2 on
                   gfx950 + WRITE_SIZE), withheld when the profile is of another kernel version.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
@@ -59,6 +63,8 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0     # wave64 fp32 VALU instructions/s: 2 cycles each per SIMD-32
 SIMD_PEAK_GCYC = 256 * 4 * 2.4           # SIMD issue-cycles per second at the nominal 2.4 GHz
+TCP_PEAK_GCYC = 256 * 2.4                # vector-L1 (TCP) cycles per second: one line look-up per CU and cycle
+TCP_CYCLES_PER_L2_LINE = 1.23            # extra TCP cycles per TCP->TCC request (profiles/r02/tcp_gather.txt)
 ENV = "double_pendulum_swingup"
 BINS = 80
 EVAL_PER_STEP = 10
@@ -147,9 +153,10 @@ def numpy_reference_c1() -> dict:
             "config": "Pendulum 50 x 50 x 11 actions, numpy float32, one thread"}
 
 
-def load_profile(n_states: int, kernel_hash: str):
-    """Latest committed PMC profile of the bench state whose kernel hash is the current one."""
-    for path in sorted(ROOT.glob("profiles/r*/counters_bench_c4.json"), reverse=True):
+def load_profile(n_states: int, kernel_hash: str, label: str = "bench"):
+    """Latest committed PMC profile of the bench (or policy-iteration: label "real") state whose
+    kernel hash is the current one."""
+    for path in sorted(ROOT.glob(f"profiles/r*/counters_{label}_c4.json"), reverse=True):
         try:
             prof = json.loads(path.read_text())
         except (OSError, ValueError):
@@ -324,6 +331,14 @@ def main() -> None:
                 if gui and prof_ms:
                     clock_ghz = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # sum over the 8 XCDs
                     e["valu"]["clock_GHz_under_profiler"] = clock_ghz
+            acc, req = k["counters"].get("TCP_TOTAL_CACHE_ACCESSES_sum"), k["counters"].get("TCP_TCC_READ_REQ_sum")
+            if acc and req is not None:
+                cyc = acc + TCP_CYCLES_PER_L2_LINE * req                # TCP cycles per launch, all CUs
+                e["l1"] = {"tcp_cache_accesses": acc, "tcp_tcc_read_requests": req,
+                           "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
+                           "achieved_Gcyc_per_s": cyc / (ms * 1e-3) / 1e9,
+                           "gather_frac": cyc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC,
+                           "source": "profiles/r02/tcp_gather.txt (tools/tcp_gather_bench.hip)"}
             if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
                 e["hbm_traffic_bytes"] = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
                 e["l2_hit_rate"] = k.get("l2_hit_rate")
@@ -334,25 +349,45 @@ def main() -> None:
         "improve_sweep": kernel_entry("pi_improve_sweep_kernel", improve_ms, states_per_launch * nA, bytes_improve),
     }
     if converged:
+        # the same two bounds for the policy-iteration state, from ITS committed counters
+        rprof, rpath = load_profile(n, khash, "real") if (args.env == ENV and args.bins == BINS) else (None, None)
+        rk = (rprof or {}).get("kernels", {}).get("pi_eval_sweep_kernel")
+        if rk:
+            c, sec = rk["counters"], converged["ms"] * 1e-3
+            converged["profile"] = rpath
+            if rk.get("issue_cycles_model"):
+                converged["valu_issue_frac"] = (rk["issue_cycles_model"]["simd_cycles_per_wave"] * c["SQ_WAVES"]
+                                                / sec / 1e9 / SIMD_PEAK_GCYC)
+            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                converged["l1_gather_frac"] = ((c["TCP_TOTAL_CACHE_ACCESSES_sum"] + TCP_CYCLES_PER_L2_LINE
+                                                * c.get("TCP_TCC_READ_REQ_sum", 0.0)) / sec / 1e9 / TCP_PEAK_GCYC)
         kernels["eval_converged_policy"] = converged
     share = {"eval_sweeps": eval_ms * EVAL_PER_STEP, "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dom = kernels["eval_sweep"] if share["eval_sweeps"] >= share["improve_sweep"] else kernels["improve_sweep"]
-    roofline = {"bound": "valu-issue", "kernel": dom["kernel"], "achieved": None, "peak": SIMD_PEAK_GCYC,
-                "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
+    roofline = {"bound": None, "kernel": dom["kernel"], "achieved": None, "peak": None,
+                "unit": "G cycles/s of the bounding unit", "frac": None, "traffic": None,
                 "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash, "profile": prof_path,
-                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
-                "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
+                "bounds": {}}
     if "valu" in dom and "issue_frac" in dom["valu"]:
         v = dom["valu"]
-        roofline["achieved"] = v["achieved_Gcyc_per_s"]
-        roofline["frac"] = v["issue_frac"]
+        roofline["bounds"]["valu-issue"] = {
+            "achieved": v["achieved_Gcyc_per_s"], "peak": SIMD_PEAK_GCYC, "unit": "G SIMD issue-cycles/s",
+            "frac": v["issue_frac"], "insts_per_wave": v["insts_per_wave"], "waves_per_launch": v["waves_per_launch"],
+            "issue_cycles_model": v["issue_cycles_model"], "valu_Ginst_per_s": v["achieved_Ginst_per_s"],
+            "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
+            "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
         roofline["clock_GHz_under_profiler"] = v.get("clock_GHz_under_profiler")
-        roofline["insts_per_wave"] = v["insts_per_wave"]
-        roofline["waves_per_launch"] = v["waves_per_launch"]
-        roofline["issue_cycles_model"] = v["issue_cycles_model"]
-        roofline["valu_Ginst_per_s"] = v["achieved_Ginst_per_s"]
-        roofline["valu_inst_rate_peak_Ginst_per_s"] = VALU_PEAK_GIPS
-        roofline["valu_inst_rate_measured_peak_Ginst_per_s"] = (prof or {}).get("valu_peak_measured_Ginst_per_s")
+    if "l1" in dom:
+        l1 = dom["l1"]
+        roofline["bounds"]["l1-gather"] = {
+            "achieved": l1["achieved_Gcyc_per_s"], "peak": TCP_PEAK_GCYC, "unit": "G vector-L1 (TCP) cycles/s",
+            "frac": l1["gather_frac"], "tcp_cache_accesses": l1["tcp_cache_accesses"],
+            "tcp_tcc_read_requests": l1["tcp_tcc_read_requests"],
+            "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
+            "peak_source": "256 CUs x 2.4 GHz, one line look-up per CU and cycle (profiles/r02/tcp_gather.txt)"}
+    if roofline["bounds"]:
+        name, b = max(roofline["bounds"].items(), key=lambda kv: kv[1]["frac"])
+        roofline.update(bound=name, achieved=b["achieved"], peak=b["peak"], unit=b["unit"], frac=b["frac"])
     if "hbm_traffic_bytes" in dom:
         roofline["traffic"] = dom["hbm_traffic_bytes"]
         roofline["traffic_vs_compulsory"] = dom["hbm_traffic_bytes"] / compulsory
