@@ -19,21 +19,20 @@ csrc/pi_comm.cpp); torch.distributed only hands the RCCL id around and times the
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
   roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a divergent gather plus
                   ~400 fp32 VALU instructions of dynamics per state; HBM is not what bounds them
-                  (27 % of 8 TB/s).  Two on-chip bounds are computed from the committed PMC profile of
-                  THIS kernel version and the launch time measured here (HIP events on the launch
-                  stream), and `roofline` is the one with the larger fraction (`bounds` has both):
-                    l1-gather  : cycles of the CU's vector L1 (TCP) = TCP_TOTAL_CACHE_ACCESSES (one
-                                 per distinct 128-B line of a wave-wide load, at least 16 per 8-byte
-                                 load) + 1.23 x TCP->TCC requests (lines that L2 serves), as measured by
-                                 tools/tcp_gather_bench.hip (profiles/r02/tcp_gather.txt);
-                                 peak = 256 CUs x 2.4 GHz = 614.4 G TCP-cycles/s;
-                    valu-issue : SIMD issue-cycles of the instruction mix = instructions per wave by
-                                 class x cycles per wave64 instruction of that class
-                                 (tools/valu_issue_bench.hip: 2.3 fp32 fma/mul/add, 4.15 other, 8.15
-                                 transcendental) x waves; peak = 256 CUs x 4 SIMDs x 2.4 GHz.
-                  frac = achieved / peak = the time the kernel needs on that unit at the NOMINAL clock
-                  over the time the launch took (the chip holds ~2.0-2.1 GHz under this load:
-                  clock_GHz_under_profiler).
+                  (27 % of 8 TB/s, `hbm_frac`).  The hard on-chip ceiling is fp32 VALU ISSUE:
+                  achieved = SIMD issue-cycles delivered per second = (instructions per wave by
+                  class, from the committed PMC profile of THIS kernel version) x (cycles per wave64
+                  instruction of that class, measured by tools/valu_issue_bench.hip: 2.3 fp32
+                  fma/mul/add, 4.15 other, 8.15 transcendental) x waves per launch / mean launch time
+                  (HIP events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz = 2457.6 G
+                  SIMD-cycles/s; frac = achieved / peak = the time the instruction mix needs at the
+                  NOMINAL clock over the time the launch took (the chip holds ~2.0-2.1 GHz under this
+                  load: clock_GHz_under_profiler).
+                  `l1_gather_model` says what the rest of the time is: the vector-L1 (TCP) path of
+                  the corner gather — line accesses + 1.23 cycles per line that L2 has to serve
+                  (tools/tcp_gather_bench.hip, profiles/r02/tcp_gather.txt, l1_path_counters.txt),
+                  as a share of the launch time.  It is a model that reproduces the time, not a
+                  peak (the improvement sweep pushes more accesses per cycle through the same unit).
                   traffic = HBM-side bytes per launch from the same profile (FETCH_SIZE x 2 on
                   gfx950 + WRITE_SIZE), withheld when the profile is of another kernel version.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
@@ -307,7 +306,7 @@ def main() -> None:
     bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
     compulsory = 13.0 * states_per_launch       # V read + V' write + policy + mask, cache-perfect
 
-    def kernel_entry(name, ms, backups, alg_bytes_per_backup):
+    def kernel_entry(name, ms, backups, alg_bytes_per_backup, l1_model=False):
         e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups,
              "backups_per_s": backups / (ms * 1e-3)}
         alg = alg_bytes_per_backup * backups / (ms * 1e-3) / 1e9
@@ -335,17 +334,19 @@ def main() -> None:
             if acc and req is not None:
                 cyc = acc + TCP_CYCLES_PER_L2_LINE * req                # TCP cycles per launch, all CUs
                 e["l1"] = {"tcp_cache_accesses": acc, "tcp_tcc_read_requests": req,
-                           "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
-                           "achieved_Gcyc_per_s": cyc / (ms * 1e-3) / 1e9,
-                           "gather_frac": cyc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC,
-                           "source": "profiles/r02/tcp_gather.txt (tools/tcp_gather_bench.hip)"}
+                           "accesses_per_CU_cycle_at_2.4GHz": acc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC}
+                if l1_model:       # the gather-bound kernel only: the improvement sweep is VALU-bound
+                    e["l1"].update({"model_cycles": cyc, "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
+                                    "model_share_of_launch_time_at_2.4GHz": cyc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC,
+                                    "source": "profiles/r02/tcp_gather.txt, l1_path_counters.txt (a model, "
+                                              "not a peak)"})
             if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
                 e["hbm_traffic_bytes"] = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
                 e["l2_hit_rate"] = k.get("l2_hit_rate")
         return e
 
     kernels = {
-        "eval_sweep": kernel_entry("pi_eval_sweep_kernel", eval_ms, states_per_launch, bytes_eval),
+        "eval_sweep": kernel_entry("pi_eval_sweep_kernel", eval_ms, states_per_launch, bytes_eval, l1_model=True),
         "improve_sweep": kernel_entry("pi_improve_sweep_kernel", improve_ms, states_per_launch * nA, bytes_improve),
     }
     if converged:
@@ -359,35 +360,30 @@ def main() -> None:
                 converged["valu_issue_frac"] = (rk["issue_cycles_model"]["simd_cycles_per_wave"] * c["SQ_WAVES"]
                                                 / sec / 1e9 / SIMD_PEAK_GCYC)
             if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-                converged["l1_gather_frac"] = ((c["TCP_TOTAL_CACHE_ACCESSES_sum"] + TCP_CYCLES_PER_L2_LINE
-                                                * c.get("TCP_TCC_READ_REQ_sum", 0.0)) / sec / 1e9 / TCP_PEAK_GCYC)
+                converged["l1_gather_model_share_of_launch_time_at_2.4GHz"] = (
+                    (c["TCP_TOTAL_CACHE_ACCESSES_sum"] + TCP_CYCLES_PER_L2_LINE * c.get("TCP_TCC_READ_REQ_sum", 0.0))
+                    / sec / 1e9 / TCP_PEAK_GCYC)
         kernels["eval_converged_policy"] = converged
     share = {"eval_sweeps": eval_ms * EVAL_PER_STEP, "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dom = kernels["eval_sweep"] if share["eval_sweeps"] >= share["improve_sweep"] else kernels["improve_sweep"]
-    roofline = {"bound": None, "kernel": dom["kernel"], "achieved": None, "peak": None,
-                "unit": "G cycles/s of the bounding unit", "frac": None, "traffic": None,
+    roofline = {"bound": "valu-issue", "kernel": dom["kernel"], "achieved": None, "peak": SIMD_PEAK_GCYC,
+                "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
                 "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash, "profile": prof_path,
-                "bounds": {}}
+                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
+                "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
     if "valu" in dom and "issue_frac" in dom["valu"]:
         v = dom["valu"]
-        roofline["bounds"]["valu-issue"] = {
-            "achieved": v["achieved_Gcyc_per_s"], "peak": SIMD_PEAK_GCYC, "unit": "G SIMD issue-cycles/s",
-            "frac": v["issue_frac"], "insts_per_wave": v["insts_per_wave"], "waves_per_launch": v["waves_per_launch"],
-            "issue_cycles_model": v["issue_cycles_model"], "valu_Ginst_per_s": v["achieved_Ginst_per_s"],
-            "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
-            "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
+        roofline["achieved"] = v["achieved_Gcyc_per_s"]
+        roofline["frac"] = v["issue_frac"]
         roofline["clock_GHz_under_profiler"] = v.get("clock_GHz_under_profiler")
+        roofline["insts_per_wave"] = v["insts_per_wave"]
+        roofline["waves_per_launch"] = v["waves_per_launch"]
+        roofline["issue_cycles_model"] = v["issue_cycles_model"]
+        roofline["valu_Ginst_per_s"] = v["achieved_Ginst_per_s"]
+        roofline["valu_inst_rate_peak_Ginst_per_s"] = VALU_PEAK_GIPS
+        roofline["valu_inst_rate_measured_peak_Ginst_per_s"] = (prof or {}).get("valu_peak_measured_Ginst_per_s")
     if "l1" in dom:
-        l1 = dom["l1"]
-        roofline["bounds"]["l1-gather"] = {
-            "achieved": l1["achieved_Gcyc_per_s"], "peak": TCP_PEAK_GCYC, "unit": "G vector-L1 (TCP) cycles/s",
-            "frac": l1["gather_frac"], "tcp_cache_accesses": l1["tcp_cache_accesses"],
-            "tcp_tcc_read_requests": l1["tcp_tcc_read_requests"],
-            "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
-            "peak_source": "256 CUs x 2.4 GHz, one line look-up per CU and cycle (profiles/r02/tcp_gather.txt)"}
-    if roofline["bounds"]:
-        name, b = max(roofline["bounds"].items(), key=lambda kv: kv[1]["frac"])
-        roofline.update(bound=name, achieved=b["achieved"], peak=b["peak"], unit=b["unit"], frac=b["frac"])
+        roofline["l1_gather_model"] = dom["l1"]
     if "hbm_traffic_bytes" in dom:
         roofline["traffic"] = dom["hbm_traffic_bytes"]
         roofline["traffic_vs_compulsory"] = dom["hbm_traffic_bytes"] / compulsory
