@@ -37,6 +37,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), plus
                   gfx950 + WRITE_SIZE), withheld when the profile is of another kernel version.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
                   launch time, for reference only: those bytes are cache hits, not a bound.
+  sweeps_to_converge — a full run() of policy iteration from V = 0 with the env's own settings (N = 1,
+                  outside the timed region; --no-full-run skips it): outer iterations, sweeps, seconds.
   kernels       — every kernel of the step, plus `eval_converged_policy`: the same evaluation
                   sweep on a policy-iteration state (3 outer iterations from V = 0), which is what
                   the sweeps of a real run() see.
@@ -177,9 +179,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converged-state", action="store_true",
                     help="skip the policy-iteration-state measurement (3 outer iterations, ~4 s)")
-    ap.add_argument("--full-run", action="store_true",
-                    help="also run policy iteration to convergence from V = 0 (the metric's 'sweeps-to-converge' "
-                         "part; ~45 s on C4) and report sweeps, outer iterations and wall time")
+    ap.add_argument("--no-full-run", action="store_true",
+                    help="skip the run of policy iteration to convergence from V = 0 (the metric's "
+                         "'sweeps-to-converge' part: sweeps, outer iterations, wall time; ~45 s on C4, "
+                         "N = 1 only, outside the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 26,
                     help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
                          "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
@@ -286,18 +289,22 @@ def main() -> None:
 
     # ── sweeps-to-converge (optional: a full run() from V = 0 with the env's own settings) ───
     full_run = None
-    if args.full_run:
-        fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
-        torch.cuda.synchronize()
-        t_run = time.perf_counter()
-        fresh.run()
-        t_run = time.perf_counter() - t_run
-        st = fresh.stats
-        full_run = {"pi_iterations": st["pi_iterations"], "eval_sweeps": st["eval_sweeps"],
-                    "improve_sweeps": st["improve_sweeps"], "stable": st.get("stable"), "seconds": t_run,
-                    "backups_per_s": n * (st["eval_sweeps"] + st["improve_sweeps"] * nA) / t_run,
-                    "us_per_eval_sweep": t_run / max(st["eval_sweeps"], 1) * 1e6}
-        del fresh
+    if world == 1 and not args.no_full_run:
+        try:
+            fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
+            torch.cuda.synchronize()
+            t_run = time.perf_counter()
+            fresh.run()
+            t_run = time.perf_counter() - t_run
+            st = fresh.stats
+            full_run = {"pi_iterations": st["pi_iterations"], "eval_sweeps": st["eval_sweeps"],
+                        "improve_sweeps": st["improve_sweeps"], "stable": st.get("stable"), "seconds": t_run,
+                        "backups_per_s": n * (st["eval_sweeps"] + st["improve_sweeps"] * nA) / t_run,
+                        "us_per_eval_sweep": t_run / max(st["eval_sweeps"], 1) * 1e6,
+                        "settings": dict(cls.CONFIG)}
+            del fresh
+        except Exception as exc:                      # never lose the timed result over the extra run
+            full_run = {"error": repr(exc)}
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
