@@ -47,3 +47,37 @@ def test_no_reference_derived_artifacts_in_the_tree():
         if re.search(r"[\"']/root/reference", p.read_text()):
             offenders.append(rel)
     assert not offenders, offenders
+
+
+def test_committed_bench_evidence_matches_the_kernels_and_the_contract():
+    """profiles/r*/bench_c4.json is the line `python bench.py` printed for the kernels in the tree:
+    it carries every field of the bench contract, its roofline was computed from counters of the
+    same kernel source (hash), and no fraction exceeds 1."""
+    import json
+    from dynamicprogramming_amd import _native
+    path = sorted(ROOT.glob("profiles/r*/bench_c4.json"))[-1]
+    d = json.loads(path.read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["ms_per_step"] * d["steps"] * 1e-3 * d["value"]
+               - d["steps"] * d["config"]["states"] * (d["config"]["eval_sweeps_per_step"]
+                                                        + d["config"]["improve_sweeps_per_step"] * d["config"]["actions"])
+               ) < 1e-6 * d["value"]                              # value = backups / elapsed
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["kernel_source_hash"] == _native.kernel_source_hash(), \
+        "kernels changed since profiles/ were made: re-run tools/profile_counters.sh and bench.py"
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["hbm_frac"] <= 1.0 and r["traffic"] > 0
+    prof = json.loads((ROOT / r["profile"]).read_text())
+    assert prof["kernel_source_hash"] == r["kernel_source_hash"]
+    for k in d["kernels"].values():
+        for name, v in (k.get("valu") or {}).items():
+            if name.endswith("frac"):
+                assert v <= 1.0, (name, v)
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
