@@ -36,6 +36,8 @@ SIGNATURES = {
                                      ctypes.c_float, _vp, _vp]),
     "pi_eval_sweeps": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, ctypes.c_int, _vp, _vp]),
+    "pi_policy_evaluation": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_double, ctypes.c_int,
+                                            ctypes.c_int, _vp, _vp, _vp, _vp]),
     "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, _vp, _vp]),
     "pi_value_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
@@ -206,6 +208,12 @@ class Engine:
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta=0, stream=0):
         _check(lib().pi_eval_sweeps(self._h, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps,
                                     d_delta or None, stream or None), "pi_eval_sweeps")
+
+    def policy_evaluation(self, V, policy, term, gamma, theta, max_sweeps, check_interval, d_sweeps, d_delta,
+                          d_residual_log, stream=0):
+        _check(lib().pi_policy_evaluation(self._h, V, policy, term, gamma, float(theta), int(max_sweeps),
+                                          int(check_interval), d_sweeps, d_delta or None, d_residual_log,
+                                          stream or None), "pi_policy_evaluation")
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
         _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,

@@ -69,13 +69,17 @@ struct pi_handle {
     hipModule_t module = nullptr;
     hipFunction_t f_eval = nullptr, f_improve = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
-                  f_probe_coords = nullptr;
+                  f_probe_coords = nullptr, f_resident = nullptr;
     int num_cu = 0;
     int block_eval = 256, block_improve = 256;   // threads per workgroup = states per chunk
     int cpw_eval = 1, cpw_improve = 1;           // chunks a workgroup sweeps
     int vgpr_eval = -1, vgpr_improve = -1;
     bool cache_hit = false;
     bool use_graphs = true;
+    // LDS-resident evaluation batches (grids of up to ~12 k states): states per thread of the one
+    // workgroup (resident_block threads), 0 = this grid is too big; the switch is pi_set_option 3
+    int resident_k = 0, resident_block = 1024;
+    bool use_resident = true;
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank

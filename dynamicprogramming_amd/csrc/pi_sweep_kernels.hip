@@ -448,6 +448,166 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
     if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
 }
 
+// ---- LDS-resident evaluation batch for small grids ----------------------------------------
+// Grids of up to PI_RESIDENT_MAX states are launch-bound: one sweep is a few microseconds of
+// launch, load -> compute -> gather latency and kernel boundary for a few thousand states of work
+// (profiles/r02/full_runs_mi355x.txt).  With a fixed policy the successor cell, its D fractional
+// offsets and the reward of a state do not change from sweep to sweep, and the whole value table
+// fits in LDS, so ONE workgroup (1024 threads in 2-D, 512 above) runs the entire batch of `n_sweeps` sweeps: the
+// dynamics once per state (results kept in registers, PI_RESIDENT_K states per thread), then per
+// sweep 2^D LDS reads and the fmaf chain per state and two workgroup barriers (Jacobi: the new
+// values wait in registers until every lane has read the old ones).  The last two iterates go to
+// the caller's buffers exactly where the ping-pong of pi_eval_sweeps puts them (sweep i writes Vb
+// for even i, Va for odd i); the residual of the last sweep goes straight to *delta_out.
+// Whole-grid batches only (the host checks): a partial range would read the other buffer's values
+// outside the range on odd sweeps.  Arithmetic identical to pi_eval_sweep_kernel's.
+// Second mode (sweeps_out != nullptr): the reference's whole policy_evaluation loop (:300-336) in
+// this one launch — up to n_sweeps sweeps, the residual looked at on sweeps 0, check_interval,
+// 2 check_interval, ... and the last one, stop as soon as it is below theta (compared in double,
+// like the host's `float(delta) < theta`); every residual looked at goes to residual_log, the
+// number of sweeps done to *sweeps_out, the newest iterate to Va (Vb is not touched).
+#ifndef PI_RESIDENT_K
+#define PI_RESIDENT_K 0
+#endif
+#if PI_RESIDENT_K > 0
+// 1024 threads (128 VGPRs each) hold 12 two-dimensional states per thread without spilling; 4-D and
+// 6-D states carry more per-state data and 2^D weights in flight: 512 threads with 256 VGPRs each.
+#ifndef PI_RESIDENT_BLOCK
+#define PI_RESIDENT_BLOCK (PI_D == 2 ? 1024 : 512)
+#endif
+#ifndef PI_RESIDENT_OVERLAP
+#define PI_RESIDENT_OVERLAP (PI_D == 2 ? 4 : PI_D == 4 ? 2 : 1)
+#endif
+__device__ __forceinline__ float pi_interpolate_lds(const float* lv, unsigned int base, const float (&fr)[PI_D]) {
+    float w[PI_C];
+    pi_corner_weights(fr, w);
+    float v[PI_C];
+#pragma unroll
+    for (int c = 0; c < PI_C; ++c) v[c] = lv[base + (unsigned int)pi_corner_offset(c)];
+    float e = 0.0f;
+#pragma unroll
+    for (int c = 0; c < PI_C; ++c) e = fmaf(w[pi_corner_mask(c)], v[c], e);
+    return e;
+}
+extern "C" __global__ void __launch_bounds__(PI_RESIDENT_BLOCK)
+pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const int* __restrict__ policy,
+                        const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                        float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
+                        int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ float lv[PI_GRID.n];                       // the value table
+    __shared__ float lds_red[PI_RESIDENT_BLOCK / 64 + 1];
+    const bool converge = sweeps_out != nullptr;
+    constexpr unsigned int N = (unsigned int)PI_GRID.n;
+    const unsigned int tid = threadIdx.x;
+    for (unsigned int i = tid; i < N; i += PI_RESIDENT_BLOCK) lv[i] = Va[i];
+    pi_stage_table<PI_RESIDENT_BLOCK>(tab, lds_tab);
+    __syncthreads();
+
+    // per state: 0 = no state (tail), 1 = terminal (copies its value), 2 = done successor (no
+    // bootstrap), 3 = interpolates
+    unsigned int kind[PI_RESIDENT_K], base[PI_RESIDENT_K];
+    float fr[PI_RESIDENT_K][PI_D], reward[PI_RESIDENT_K], v_cur[PI_RESIDENT_K];
+#pragma unroll
+    for (int j = 0; j < PI_RESIDENT_K; ++j) {
+        const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+        kind[j] = 0u;
+        base[j] = 0u;
+        reward[j] = 0.0f;
+        v_cur[j] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d) fr[j][d] = 0.0f;
+        if (s < N) {
+            v_cur[j] = lv[s];
+            kind[j] = 1u;
+            if (!term[s]) {
+                float x[PI_D], ns[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                bool done;
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + policy[s]], ns, &reward[j], &done);
+                kind[j] = 2u;
+                if (!done) {
+                    pi_locate(ns, base[j], fr[j]);
+                    kind[j] = 3u;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                // one state at a time: the per-state results
+    }                                                     // fill the register file, not the temporaries
+
+    float dmax = 0.0f;
+    int done_sweeps = 0;
+    for (int i = 0; i < n_sweeps; ++i) {
+        // Branch-free per state, so that the LDS reads of several states are in flight together:
+        // states that do not interpolate read cell 0 (their `base`) and drop the result by select.
+        float nv[PI_RESIDENT_K];
+#pragma unroll
+        for (int j = 0; j < PI_RESIDENT_K; ++j) {
+            const float e = pi_interpolate_lds(lv, base[j], fr[j]);
+            const float q = reward[j] + gamma * (kind[j] == 3u ? e : 0.0f);
+            nv[j] = kind[j] >= 2u ? q : v_cur[j];
+            // let PI_RESIDENT_OVERLAP states overlap, no more (registers)
+            if ((j + 1) % PI_RESIDENT_OVERLAP == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                  // every lane has read the old table
+        const bool last = i == n_sweeps - 1;
+        const bool keep = !converge && i >= n_sweeps - 2; // batch mode: the two iterates the caller sees
+        const bool look = last || (converge && i % check_interval == 0);
+        float* dst = (i & 1) ? Va : Vb;
+        if (look) dmax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PI_RESIDENT_K; ++j) {
+            const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+            if (kind[j] != 0u) {
+                lv[s] = nv[j];
+                if (keep) dst[s] = nv[j];
+            }
+            const float dlt = fabsf(nv[j] - v_cur[j]);    // 0 for lanes without a state (nv = v_cur = 0)
+            dmax = (look & (dlt > dmax)) ? dlt : dmax;
+            v_cur[j] = nv[j];
+        }
+        done_sweeps = i + 1;
+        if (converge && look) {                           // workgroup-wide residual, then decide together
+            const float wmax = pi_wave_max(dmax);
+            if ((tid & 63u) == 0u) lds_red[tid >> 6] = wmax;
+            __syncthreads();
+            if (tid == 0u) {
+                float m = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < PI_RESIDENT_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
+                lds_red[PI_RESIDENT_BLOCK / 64] = m;
+                residual_log[i / check_interval + ((last && i % check_interval != 0) ? 1 : 0)] = m;
+            }
+            __syncthreads();                              // also: the new table is complete
+            if ((double)lds_red[PI_RESIDENT_BLOCK / 64] < theta) break;
+        } else {
+            __syncthreads();                              // the new table is complete
+        }
+    }
+    if (converge) {
+#pragma unroll
+        for (int j = 0; j < PI_RESIDENT_K; ++j) {
+            const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+            if (kind[j] != 0u) Va[s] = v_cur[j];
+        }
+        if (tid == 0u) {
+            *sweeps_out = done_sweeps;
+            if (delta_out != nullptr) *delta_out = lds_red[PI_RESIDENT_BLOCK / 64];
+        }
+    } else if (delta_out != nullptr) {
+        dmax = pi_wave_max(dmax);
+        if ((tid & 63u) == 0u) lds_red[tid >> 6] = dmax;
+        __syncthreads();
+        if (tid == 0u) {
+            float m = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < PI_RESIDENT_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
+            *delta_out = m;
+        }
+    }
+}
+#endif
+
 // ---- greedy policy improvement sweep -------------------------------------------
 // policy[s] = argmax_a [ r(s,a) + gamma * E[V](s'_a) ], first maximum wins; terminal
 // states keep their entry.  changed (nullable): slots counting the entries that changed.

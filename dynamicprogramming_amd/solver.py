@@ -92,6 +92,27 @@ class HipSweepBackend:
                                 s_begin, s_end, gamma, n_sweeps,
                                 0 if d_delta is None else d_delta.data_ptr(), self._stream())
 
+    @property
+    def resident(self) -> bool:
+        """True when the grid is small enough for the library's LDS-resident kernel, which runs a
+        whole policy evaluation (all sweeps and residual checks) in one launch."""
+        return self.engine.info(13) > 0 and self.engine.info(14) == 1
+
+    def policy_evaluation(self, V, policy, term, gamma, theta, max_sweeps, check_interval):
+        """The whole evaluation loop on the device (pi_policy_evaluation): returns (sweeps done,
+        the residuals looked at, in order).  One host synchronisation for the whole evaluation."""
+        torch = self.torch
+        looks = max_sweeps // check_interval + 2
+        out = torch.zeros(looks + 1, dtype=torch.float32, device=self.device)     # [log..., sweeps as int32 bits]
+        sweeps = out[looks:].view(torch.int32)
+        self.engine.policy_evaluation(V.data_ptr(), policy.data_ptr(), term.data_ptr(), gamma, theta,
+                                      max_sweeps, check_interval, sweeps.data_ptr(), 0, out.data_ptr(),
+                                      self._stream())
+        host = out.cpu()
+        done = int(host[looks:].view(torch.int32).item())
+        n_looks = (done - 1) // check_interval + 1 + (1 if (done - 1) % check_interval else 0)
+        return done, host[:n_looks].numpy()
+
     def reach_planes(self, term, s_begin, s_end, n_planes, dim=0):
         """bool[n_planes]: planes of V along `dim` the states of the range can read (any action)."""
         words = (n_planes + 31) // 32
@@ -319,6 +340,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         gamma = float(np.float32(cfg.gamma))
         delta = float("inf")
         t0 = time.perf_counter()
+        if self._comm is None and getattr(self._backend, "resident", False) and cfg.max_eval_iter >= 1:
+            return self._policy_evaluation_resident(gamma, t0)
         i = 0
         sweeps = 0
         while i < cfg.max_eval_iter:
@@ -336,6 +359,29 @@ class _CudaPolicyIterationBase(abc.ABC):
                 break
         else:
             logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+        self.stats["eval_sweeps"] += sweeps
+        self.stats["sweeps_per_iter"].append(sweeps)
+        self.stats["eval_seconds"] += time.perf_counter() - t0
+        return delta
+
+    def _policy_evaluation_resident(self, gamma: float, t0: float) -> float:
+        """Small grids: the same loop, run by ONE kernel launch with V in LDS (same sweeps, same
+        residuals, same V); the log lines are written afterwards from the residuals it recorded."""
+        cfg = self.config
+        sweeps, looked = self._backend.policy_evaluation(self.d_value_function, self.d_policy,
+                                                         self.d_terminal_mask, gamma, float(cfg.theta),
+                                                         int(cfg.max_eval_iter), SYNC_INTERVAL)
+        delta = float(looked[-1])
+        for k, r in enumerate(looked):
+            check = min(k * SYNC_INTERVAL, cfg.max_eval_iter - 1)
+            if check % cfg.log_interval == 0:
+                logger.debug(f"  Eval iter {check:5d} | delta = {float(r):.4e}")
+        last = sweeps - 1
+        if delta < cfg.theta:
+            logger.success(f"  Eval converged at iter {last} | delta = {delta:.2e}")
+        else:
+            logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+        self._d_delta.fill_(delta)
         self.stats["eval_sweeps"] += sweeps
         self.stats["sweeps_per_iter"].append(sweeps)
         self.stats["eval_seconds"] += time.perf_counter() - t0

@@ -94,11 +94,28 @@ int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* poli
  * The newest iterate is in Vb when n_sweeps is odd, in Va when even.
  * Ranges of up to 2^20 states are launch-bound (a few microseconds per sweep): there the whole
  * batch, including the residual fold, is replayed as ONE hipGraph (built on first use per
- * argument set, cached in the handle) instead of n_sweeps host launches.
+ * argument set, cached in the handle) instead of n_sweeps host launches.  Grids of up to 12 288
+ * states (4 096 in 4-D, 1 024 in 6-D) swept whole go further: ONE workgroup keeps the value table in LDS and
+ * each state's successor cell, weights and reward in registers and runs the entire batch in one
+ * launch (pi_eval_resident_kernel); the two newest iterates land in Va / Vb as above.
  */
 int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
                    const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,
                    int n_sweeps, float* d_delta, void* stream);
+
+/*
+ * The whole policy_evaluation loop (:300-336) in ONE launch, for grids the LDS-resident kernel
+ * holds (pi_info 13 > 0; fails otherwise): up to max_sweeps Jacobi sweeps of the whole grid under
+ * `policy`, the residual looked at on sweeps 0, check_interval, 2 check_interval, ... (the
+ * reference's SYNC_INTERVAL = 25) and on the last one, stopping at the first residual below theta.
+ * V is updated in place (the newest iterate); *d_sweeps receives the number of sweeps done,
+ * *d_delta (nullable) the last residual looked at, d_residual_log[k] every residual looked at
+ * (k-th look; at least max_sweeps / check_interval + 2 floats).  Same arithmetic, same sweep
+ * count and same V as the same loop driven from the host through pi_eval_sweeps.
+ */
+int pi_policy_evaluation(pi_handle* h, float* V, const int32_t* policy, const uint8_t* term, float gamma,
+                         double theta, int max_sweeps, int check_interval, int32_t* d_sweeps, float* d_delta,
+                         float* d_residual_log, void* stream);
 
 /*
  * Greedy improvement over [s_begin, s_end): policy[s] = argmax_a Q(s, a), first
@@ -209,14 +226,16 @@ int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, 
 int pi_probe_coords(pi_handle* h, int64_t s_begin, int64_t s_end, float* out, int chunks_per_workgroup,
                     void* stream);
 
-/* Tuning: 0 = 256-state chunks per workgroup of the evaluation sweeps, 1 = of the improvement /
- * value sweeps (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1). */
+/* Tuning: 0 = chunks per workgroup of the evaluation sweeps, 1 = of the improvement / value sweeps
+ * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of
+ * small grids in the LDS-resident kernel (0 | 1).  Results do not depend on any of them. */
 int pi_set_option(pi_handle* h, int what, int64_t value);
 
 /* Introspection: 0 n_states, 1 n_actions, 2 D, 3 chunks per workgroup (evaluation), 4 VGPRs of the
  * eval kernel, 5 VGPRs of the improve kernel, 6 compute units, 7 = 1 if the last pi_compile was
  * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
- * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
+ * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
+ * batch kernel (0: grid too big for it), 14 that kernel enabled, 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
 
 #ifdef __cplusplus

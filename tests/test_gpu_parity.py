@@ -500,6 +500,114 @@ def test_chunks_per_workgroup_change_speed_not_results(name, shape, cuda_device)
     eng.close()
 
 
+@pytest.mark.parametrize("name,shape", [("pendulum", (50, 50)), ("mountain_car", (111, 110)),
+                                        ("cartpole", (8, 7, 9, 8)), ("overhead_crane", (8, 8, 8, 8)),
+                                        ("double_pendulum_swingup", (7, 6, 9, 5)),
+                                        ("double_cartpole", (3, 3, 4, 3, 3, 3)),
+                                        ("double_cartpole_swingup", (2, 3, 3, 4, 3, 4))])
+def test_small_grids_run_whole_batches_in_lds(name, shape, cuda_device):
+    """Grids that fit one workgroup's LDS and registers run a whole batch of evaluation sweeps in
+    ONE launch (pi_eval_resident_kernel); both iterates the caller sees and the residual equal the
+    sweep-by-sweep launches bit for bit, for odd, even and minimal batch lengths, with terminal
+    states and done successors in the grid."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, seed=11)
+    n = len(states)
+    assert eng.info(13) > 0 and eng.info(14) == 1, "this grid should qualify for the resident kernel"
+    gamma = float(np.float32(0.985))
+    d_pol, d_term = _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
+    junk = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+    for n_sweeps in (2, 3, 25, 26):
+        out = {}
+        for resident in (1, 0):
+            eng.set_option(3, resident)
+            eng.set_option(2, 0)                   # the comparison path: plain launches, no graph
+            A, B = _dev(V, cuda_device), _dev(junk, cuda_device)
+            d_delta = torch.full((1,), -1.0, dtype=torch.float32, device=cuda_device)
+            eng.eval_sweeps(A.data_ptr(), B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
+                            n_sweeps, d_delta.data_ptr())
+            torch.cuda.synchronize()
+            out[resident] = (A.cpu().numpy(), B.cpu().numpy(), np.float32(d_delta.item()))
+        H.assert_bits_equal(out[1][0], out[0][0], f"Va after {n_sweeps} sweeps")
+        H.assert_bits_equal(out[1][1], out[0][1], f"Vb after {n_sweeps} sweeps")
+        H.assert_bits_equal(out[1][2], out[0][2], "residual")
+    # against the oracle as well (one batch of 3)
+    chk = H.oracle_for(name)
+    cur = V.copy()
+    for _ in range(3):
+        cur, o_delta = chk.eval_sweep(states, acts, pol, cur, term, lo, hi, gshape, strides, gamma)
+    eng.set_option(3, 1)
+    A, B = _dev(V, cuda_device), torch.zeros(n, dtype=torch.float32, device=cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweeps(A.data_ptr(), B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 3,
+                    d_delta.data_ptr())
+    H.assert_bits_equal(B.cpu().numpy(), cur, "third iterate vs oracle")
+    H.assert_bits_equal(np.float32(d_delta.item()), np.float32(o_delta), "residual vs oracle")
+    # a partial range never takes the resident path (it would see the wrong values outside the range)
+    a, b = n // 5, n - n // 7
+    res = {}
+    for resident in (1, 0):
+        eng.set_option(3, resident)
+        A, B = _dev(V, cuda_device), _dev(junk, cuda_device)
+        eng.eval_sweeps(A.data_ptr(), B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, 4, 0)
+        res[resident] = (A.cpu().numpy(), B.cpu().numpy())
+    H.assert_bits_equal(res[1][0], res[0][0], "partial range Va")
+    H.assert_bits_equal(res[1][1], res[0][1], "partial range Vb")
+    eng.close()
+
+
+@pytest.mark.parametrize("name,bins,max_eval", [("pendulum", 50, 5000), ("mountain_car", 64, 300),
+                                                ("cartpole", 8, 5000), ("double_pendulum_swingup", 8, 777)])
+def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, cuda_device, monkeypatch):
+    """pi_policy_evaluation runs the reference's evaluation loop (sweeps, the residual looked at on
+    sweeps 0, 25, 50, ... and the last, stop below theta) in one launch with V in LDS: same number
+    of sweeps, same residual, same V — and the same full run() — as the host-driven loop."""
+    torch = _torch()
+    cfg = dict(envs.ENVS[name].CONFIG, max_eval_iter=max_eval, max_pi_iter=6)
+    solvers = {}
+    for resident in ("1", "0"):
+        monkeypatch.setenv("PI_MI355_RESIDENT", resident)
+        s = envs.make(name, bins, config=envs.CudaPIConfig(**cfg), device=cuda_device)
+        assert s._backend.resident == (resident == "1")
+        solvers[resident] = s
+    a, b = solvers["1"], solvers["0"]
+    # one evaluation from the same start (zero V, zero policy; cartpole has terminal states)
+    da, db = a.policy_evaluation(), b.policy_evaluation()
+    assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"]
+    H.assert_bits_equal(np.float32(da), np.float32(db), "residual of the evaluation")
+    H.assert_bits_equal(a.d_value_function.cpu().numpy(), b.d_value_function.cpu().numpy(), "V after evaluation")
+    # the C ABI call by itself: residuals looked at == the host loop's, sweep by sweep
+    n = a.n_states
+    V = torch.zeros(n, dtype=torch.float32, device=cuda_device)
+    V2, scratch = V.clone(), torch.zeros(n, dtype=torch.float32, device=cuda_device)
+    sweeps, looked = a._backend.policy_evaluation(V, a.d_policy, a.d_terminal_mask, float(np.float32(0.95)), 1e-3, 130, 25)
+    eng = b._backend.engine
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    host_looked, i = [], 0
+    src, dst = V2, scratch
+    while i < 130:
+        check = i if i % 25 == 0 else min((i // 25 + 1) * 25, 129)
+        check = min(check, 129)
+        k = check - i + 1
+        eng.eval_sweeps(src.data_ptr(), dst.data_ptr(), b.d_policy.data_ptr(), b.d_terminal_mask.data_ptr(), 0, n,
+                        float(np.float32(0.95)), k, d_delta.data_ptr())
+        if k & 1:
+            src, dst = dst, src
+        i = check + 1
+        host_looked.append(np.float32(d_delta.item()))
+        if host_looked[-1] < 1e-3:
+            break
+    assert sweeps == i
+    H.assert_bits_equal(np.asarray(looked, np.float32), np.asarray(host_looked, np.float32), "residuals looked at")
+    H.assert_bits_equal(V.cpu().numpy(), src.cpu().numpy(), "V of the C ABI call")
+    # and whole runs
+    for s in (a, b):
+        s.run()
+    assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"] and a.stats["pi_iterations"] == b.stats["pi_iterations"]
+    H.assert_bits_equal(a.value_function, b.value_function, "V after run()")
+    assert np.array_equal(a.policy, b.policy)
+
+
 def test_small_batches_replay_as_graphs(cuda_device):
     """pi_eval_sweeps on a launch-bound range builds one hipGraph per argument set and replays it;
     results equal the eager launches' (graphs off) bit for bit, for both ping-pong orders."""
@@ -510,6 +618,7 @@ def test_small_batches_replay_as_graphs(cuda_device):
     gamma = float(np.float32(0.99))
     d_pol, d_term = _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
     results = {}
+    eng.set_option(3, 0)                           # keep the LDS-resident kernel out of this test
     for graphs in (1, 0):
         eng.set_option(2, graphs)
         A, B = _dev(V, cuda_device), torch.zeros(n, dtype=torch.float32, device=cuda_device)
