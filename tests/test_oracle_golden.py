@@ -52,8 +52,8 @@ def test_product_arithmetic_close_to_libm(name):
     """pi_math mode (the product's sinf/cosf) vs glibc mode: same indices, ulp-level values."""
     g = H.golden(name)
     nxt, rew, term = H.oracle_for(name).step(g["step_states"], g["step_actions"])
-    np.testing.assert_allclose(nxt, g["step_next"], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(rew, g["step_reward"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(nxt, g["step_next"], rtol=5e-6, atol=5e-6)        # measured 1.1e-6
+    np.testing.assert_allclose(rew, g["step_reward"], rtol=5e-6, atol=5e-6)      # measured 6.2e-7
     shape = g["g1_shape"]
     bins = H.env_bins(name, shape)
     lo, hi, gshape, strides = oracle.grid_metadata(bins)
@@ -62,11 +62,12 @@ def test_product_arithmetic_close_to_libm(name):
     Vn, _ = chk.eval_sweep(states, g["actions"], g["g1_policy"], g["g1_V"], g["g1_term"], lo, hi,
                            gshape, strides, float(g["gamma"]))
     gV = g["g1_V_next"]
-    assert np.all(np.abs(Vn - gV) <= 2e-4 * np.maximum(1.0, np.abs(gV)))
+    assert np.all(np.abs(Vn - gV) <= 1e-5 * np.maximum(1.0, np.abs(gV)))         # measured: <= 2.3e-6
     pol_n, _ = chk.improve_sweep(states, g["actions"], g["g1_policy"], g["g1_V"], g["g1_term"], lo,
                                  hi, gshape, strides, float(g["gamma"]))
-    firm = g["g1_q_gap"] > 1e-3
-    assert np.array_equal(pol_n[firm], g["g1_policy_next"][firm])
+    firm = g["g1_q_gap"] > 1e-5 * max(1.0, float(np.abs(gV).max()))
+    assert np.array_equal(pol_n[firm], g["g1_policy_next"][firm])                # measured: no mismatch anywhere
+    assert np.mean(pol_n == g["g1_policy_next"]) >= 0.999
 
 
 def test_c1_run_reproduces_reference_text_run():
@@ -88,8 +89,8 @@ def test_c1_run_reproduces_reference_text_run():
     res2 = H.oracle_for("pendulum").run(states, g["actions"], np.zeros(len(states), bool), lo, hi,
                                         gshape, strides, **kw)
     assert res2["outer_iterations"] == 14
-    assert np.mean(res2["policy"] == g["policy"]) >= 0.995
-    assert np.max(np.abs(res2["value_function"] - g["value_function"])) <= 2e-4 * np.max(np.abs(g["value_function"]))
+    assert np.mean(res2["policy"] == g["policy"]) >= 0.999                       # measured: identical
+    assert np.max(np.abs(res2["value_function"] - g["value_function"])) <= 2e-6 * np.max(np.abs(g["value_function"]))  # measured 4.3e-7
 
 
 @pytest.mark.parametrize("name", ["mountain_car", "continuous_mountain_car"])
