@@ -683,7 +683,9 @@ def test_interpolation_division_guard_edges(cuda_device):
 @pytest.mark.parametrize("mode", ["halo", "allgather"])
 @pytest.mark.parametrize("world,name,shape", [(2, "pendulum", (41, 13)),
                                                (3, "double_pendulum_swingup", (14, 9, 11, 8)),
-                                               (2, "double_cartpole", (6, 4, 5, 4, 5, 4))])
+                                               (2, "double_cartpole", (6, 4, 5, 4, 5, 4)),
+                                               (4, "cartpole_swingup", (18, 7, 9, 8)),
+                                               (8, "double_pendulum_swingup", (40, 6, 8, 6))])   # C4 @ 8 in small
 def test_sharded_driver_local_transport(world, name, shape, mode, cuda_device, monkeypatch):
     """pi_eval_sweeps_sharded / pi_improve_sweep_sharded / pi_exchange_plan (csrc/pi_comm.cpp) with
     `world` logical ranks on ONE GPU: one host thread, one stream, one set of V buffers per rank,
