@@ -43,6 +43,8 @@ SIGNATURES = {
     "pi_value_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_float, _vp, _vp, _vp]),
     "pi_reach_planes": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    "pi_reach_depth_max": (ctypes.c_int, [_vp]),
+    "pi_reach_units": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
     "pi_comm_unique_id": (ctypes.c_int, [_vp]),
     "pi_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "pi_comm_init_local": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
@@ -142,7 +144,7 @@ def comm_unique_id() -> bytes:
 
 def plan_segments(world, g0, stride0, n_states, per, reach) -> np.ndarray:
     """Host-only planner of the halo exchange (pi_plan_segments): reach is a (world, g0) bool
-    array; returns an (m, 4) int64 array of {src, dst, a, b}."""
+    array over g0 units of stride0 consecutive states each (planes of dimension 0, or rows (i0, i1)); returns an (m, 4) int64 array of {src, dst, a, b}."""
     r = np.ascontiguousarray(reach, dtype=np.uint8)
     assert r.shape == (world, g0)
     fn = lib().pi_plan_segments
@@ -226,6 +228,13 @@ class Engine:
     def reach_planes(self, term, s_begin, s_end, d_bitmap, stream=0, dim=0):
         _check(lib().pi_reach_planes(self._h, term, s_begin, s_end, int(dim), d_bitmap, stream or None),
                "pi_reach_planes")
+
+    def reach_depth_max(self) -> int:
+        return int(lib().pi_reach_depth_max(self._h))
+
+    def reach_units(self, term, s_begin, s_end, depth, d_bitmap, stream=0):
+        _check(lib().pi_reach_units(self._h, term, s_begin, s_end, int(depth), d_bitmap, stream or None),
+               "pi_reach_units")
 
     def probe_coords(self, s_begin, s_end, out, chunks_per_workgroup=1, stream=0):
         _check(lib().pi_probe_coords(self._h, s_begin, s_end, out, int(chunks_per_workgroup),

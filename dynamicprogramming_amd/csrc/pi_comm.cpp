@@ -49,6 +49,7 @@ struct Comm {
 struct ShardPlan {
     int64_t per = 0, s_begin = 0, s_end = 0;
     bool halo = false;
+    int depth = 1;                                           // granularity of the reach probe
     struct Seg { int src, dst; int64_t a, b; };
     std::vector<Seg> segs;                                   // only those that involve this rank
     std::vector<std::pair<int64_t, int64_t>> send_ranges, interior;
@@ -361,6 +362,7 @@ int pi_comm_info(pi_handle* h, int what) {
         case 1: return h->comm->world;
         case 2: return std::strcmp(h->comm->kind(), "rccl") == 0 ? 1 : 2;
         case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
+        case 4: return h->plan ? h->plan->depth : 0;
         default: return -1;
     }
 }
@@ -438,10 +440,17 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
     pi::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     pi::Comm* c = h->comm;
-    const int64_t n = h->n_states, g0 = h->shape[0], stride0 = n / g0;
+    // Units the reach is measured in: rows (i0, i1) where the grid has them (2-4x fewer values to
+    // exchange than whole planes of dimension 0), planes otherwise; PI_MI355_REACH_DEPTH overrides.
+    int depth = pi_reach_depth_max(h);
+    if (const char* e = std::getenv("PI_MI355_REACH_DEPTH")) depth = std::max(1, std::min(depth, std::atoi(e)));
+    int64_t g0 = 1;
+    for (int d = 0; d < depth; ++d) g0 *= h->shape[d];
+    const int64_t n = h->n_states, stride0 = n / g0;
     if (per * c->world < n) return fail("per * world < n_states");
     std::unique_ptr<pi::ShardPlan> plan(new pi::ShardPlan);
     plan->per = per;
+    plan->depth = depth;
     plan->s_begin = std::min((int64_t)c->rank * per, n);
     plan->s_end = std::min(plan->s_begin + per, n);
     if (mode != 1) {
@@ -451,7 +460,7 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
         uint8_t* d_all = nullptr;
         PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
         std::vector<uint32_t> bits(words, 0u);
-        int rc = pi_reach_planes(h, term, plan->s_begin, plan->s_end, 0, d_bits, stream);
+        int rc = pi_reach_units(h, term, plan->s_begin, plan->s_end, depth, d_bits, stream);
         if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
         (void)hipFree(d_bits);
@@ -491,11 +500,21 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
         for (const auto& s : plan->segs)
             if (s.src == c->rank) cuts.push_back({s.a, s.b});
         std::sort(cuts.begin(), cuts.end());
+        // What is swept first may be coarser than what is sent: pieces less than two planes of
+        // dimension 0 (at least 2^16 states) apart become ONE launch, so a shard is still swept
+        // in about three launches (low boundary planes, high boundary planes, interior) although
+        // the segments that travel are single rows.
+        const int64_t gap = std::max<int64_t>(int64_t(1) << 16, 2 * (n / h->shape[0]));
         for (const auto& r : cuts) {
-            if (!plan->send_ranges.empty() && r.first <= plan->send_ranges.back().second)
+            if (!plan->send_ranges.empty() && r.first <= plan->send_ranges.back().second + gap)
                 plan->send_ranges.back().second = std::max(plan->send_ranges.back().second, r.second);
             else
                 plan->send_ranges.push_back(r);
+        }
+        // a sliver between the shard's edge and its first / last send range joins that range
+        if (!plan->send_ranges.empty()) {
+            if (plan->send_ranges.front().first - plan->s_begin < gap) plan->send_ranges.front().first = plan->s_begin;
+            if (plan->s_end - plan->send_ranges.back().second < gap) plan->send_ranges.back().second = plan->s_end;
         }
         int64_t pos = plan->s_begin;
         for (const auto& r : plan->send_ranges) {

@@ -68,7 +68,7 @@ struct pi_handle {
     unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed
     hipModule_t module = nullptr;
     hipFunction_t f_eval = nullptr, f_improve = nullptr, f_value = nullptr, f_finalize = nullptr,
-                  f_reach_planes = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
+                  f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr, f_resident = nullptr;
     int num_cu = 0;
     int block_eval = 256, block_improve = 256;   // threads per workgroup = states per chunk

@@ -769,6 +769,68 @@ pi_reach_planes_kernel(const unsigned char* __restrict__ term, const float* __re
         if (lds_bits[i] != 0u) atomicOr(&bitmap[i], lds_bits[i]);
 }
 
+// The same question at a finer grain: "units" = the leading `depth` dimensions flattened (depth 1:
+// the planes of dimension 0 again; depth 2: the rows (i0, i1), each stride[1] contiguous states).
+// Every env moves a position by dt * velocity, so which neighbouring planes a state reads depends
+// on the sign and size of its velocity coordinate: the (plane, row) bitmap of a shard is a
+// triangle, 2-4x smaller than the band of whole planes (profiles/r02/halo_granularity.txt), and the
+// rows are still contiguous runs of V, so the exchange plan is the same planner on finer units.
+constexpr int pi_unit_count(int depth) {
+    int u = 1;
+    for (int d = 0; d < depth; ++d) u *= PI_GRID.g[d];
+    return u;
+}
+constexpr int pi_reach_depth_max() {
+    return (PI_D >= 3 && (long long)PI_GRID.g[0] * PI_GRID.g[1] <= (1LL << 17)) ? 2 : 1;
+}
+#define PI_UNIT_WORDS ((pi_unit_count(pi_reach_depth_max()) + 31) / 32)
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_reach_units_kernel(const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                      long long s_begin, long long s_end, unsigned int* __restrict__ bitmap,
+                      int depth, int cpw) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ unsigned int lds_bits[PI_UNIT_WORDS];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const long long chunk_end = min(chunk0 + cpw, n_chunks);
+    pi_stage_table<PI_BLOCK>(tab, lds_tab);
+    for (int i = threadIdx.x; i < PI_UNIT_WORDS; i += PI_BLOCK) lds_bits[i] = 0u;
+    __syncthreads();
+    constexpr unsigned int g1 = PI_D >= 2 ? PI_GRID.g[1] : 1;
+    constexpr unsigned int st0 = PI_GRID.stride[0], st1 = PI_D >= 2 ? PI_GRID.stride[1] : 1;
+    for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
+        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
+        if (s >= s_end || term[s]) continue;
+        float x[PI_D];
+        pi_state_coords((unsigned int)s, lds_tab, x);
+        int last = -1;
+        for (int a = 0; a < PI_NA; ++a) {
+            float ns[PI_D], reward, fr[PI_D];
+            bool done;
+            pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
+            if (done) continue;
+            unsigned int base;
+            pi_locate(ns, base, fr);
+            const unsigned int c0 = base / st0;
+            const int u = depth >= 2 ? (int)(c0 * g1 + (base / st1) % g1) : (int)c0;
+            if (u == last) continue;
+            last = u;
+            // the cell's corners along the leading dimensions: +1 in each of them
+            atomicOr(&lds_bits[u >> 5], 1u << (u & 31));
+            if (depth >= 2) {
+                atomicOr(&lds_bits[(u + 1) >> 5], 1u << ((u + 1) & 31));
+                atomicOr(&lds_bits[(u + (int)g1) >> 5], 1u << ((u + (int)g1) & 31));
+                atomicOr(&lds_bits[(u + (int)g1 + 1) >> 5], 1u << ((u + (int)g1 + 1) & 31));
+            } else {
+                atomicOr(&lds_bits[(u + 1) >> 5], 1u << ((u + 1) & 31));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PI_UNIT_WORDS; i += PI_BLOCK)
+        if (lds_bits[i] != 0u) atomicOr(&bitmap[i], lds_bits[i]);
+}
+
 // ---- plugin probe (parity tests for the env dynamics and the interpolation) ------
 // One thread per query point: runs step_dynamics on (state, action) and, when `idxs`
 // is given, the interpolation of an arbitrary point.  Not on the hot path.

@@ -121,6 +121,15 @@ class HipSweepBackend:
         bits = bitmap.cpu().numpy().view(np.uint32)
         return ((bits[np.arange(n_planes) >> 5] >> (np.arange(n_planes) & 31).astype(np.uint32)) & 1).astype(bool)
 
+    def reach_units(self, term, s_begin, s_end, depth):
+        """bool[units]: units of the leading `depth` dimensions (planes of dimension 0, or rows
+        (i0, i1)) the states of the range can read under any action (pi_reach_units)."""
+        n_units = int(np.prod(self.engine._shape[:depth]))
+        bitmap = self.torch.zeros((n_units + 31) // 32, dtype=self.torch.int32, device=self.device)
+        self.engine.reach_units(term.data_ptr(), s_begin, s_end, depth, bitmap.data_ptr(), self._stream())
+        bits = bitmap.cpu().numpy().view(np.uint32)
+        return ((bits[np.arange(n_units) >> 5] >> (np.arange(n_units) & 31).astype(np.uint32)) & 1).astype(bool)
+
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), term.data_ptr(), s_begin, s_end,
                                   gamma, 0 if d_changed is None else d_changed.data_ptr(),

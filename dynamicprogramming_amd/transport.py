@@ -4,8 +4,8 @@ Multi-rank transports of the policy-iteration solver.
 Partition (both transports): rank r owns the contiguous state range
 ``[r * per, min((r + 1) * per, n))``, ``per = ceil(n / world)``; every rank keeps full-size V
 buffers of ``per * world`` floats, sweeps its shard and then makes the new values visible where
-the other ranks will read them — a halo exchange of exactly the dimension-0 plane runs each peer
-can reach, or an all-gather of the shards when those bands cover most of the grid anyway.
+the other ranks will read them — a halo exchange of exactly the runs of rows (i0, i1) — planes of
+dimension 0 on 2-D grids — each peer can reach, or an all-gather of the shards when those bands cover most of the grid anyway.
 
 * ``NativeTransport`` — the product path.  Everything after construction happens inside
   libpi_mi355.so (csrc/pi_comm.cpp): RCCL communicator, exchange plan, the 25-sweep batch with
@@ -134,11 +134,16 @@ class TorchDistTransport:
         self.segments = self._send_ranges = self._interior = self._poison = None
         if mode == "allgather":
             return
-        g0, n, per = int(solver.grid_shape[0]), solver.n_states, solver._shard_len
+        n, per = solver.n_states, solver._shard_len
+        # same units as the library: rows (i0, i1) where the grid has them, planes otherwise
+        shape = [int(x) for x in solver.grid_shape]
+        depth = 2 if (len(shape) >= 3 and shape[0] * shape[1] <= (1 << 17)) else 1
+        depth = max(1, min(depth, int(os.environ.get("PI_MI355_REACH_DEPTH", depth))))
+        g0 = int(np.prod(shape[:depth]))
         stride0 = n // g0
         mine = np.zeros(g0, dtype=bool)
         if solver._s_end > solver._s_begin:
-            mine = solver._backend.reach_planes(solver.d_terminal_mask, solver._s_begin, solver._s_end, g0)
+            mine = solver._backend.reach_units(solver.d_terminal_mask, solver._s_begin, solver._s_end, depth)
         allbits = torch.zeros(self.world * g0, dtype=torch.uint8)
         dist.all_gather_into_tensor(allbits, torch.from_numpy(mine.astype(np.uint8)), group=self.group)
         reach = allbits.numpy().astype(bool).reshape(self.world, g0)

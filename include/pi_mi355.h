@@ -151,6 +151,19 @@ int pi_value_sweep(pi_handle* h, const float* V, float* Vnew, int32_t* policy, c
 int pi_reach_planes(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end, int dim,
                     uint32_t* d_bitmap, void* stream);
 
+/*
+ * The same question at a finer grain.  "Units" are the leading `depth` dimensions flattened: depth 1
+ * = the planes of dimension 0, depth 2 = the rows (i0, i1), each a contiguous run of
+ * n_states / (grid_shape[0] * grid_shape[1]) states.  d_bitmap (device, ceil(units / 32) words,
+ * zeroed here) receives one bit per unit some state of [s_begin, s_end) can read under ANY action.
+ * Every env moves a position by dt * velocity, so the rows a shard reaches in a neighbouring plane
+ * are the ones with the right sign and size of velocity: 2-4x fewer values than whole planes.
+ * pi_reach_depth_max: 2 for grids of three or more dimensions with up to 2^17 such rows, else 1.
+ */
+int pi_reach_depth_max(pi_handle* h);
+int pi_reach_units(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end, int depth,
+                   uint32_t* d_bitmap, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU (one process per GPU, RCCL over xGMI).  SURVEY.md section 8b/8e: the reference is a
  * single-device loop (:300-336), so these entry points have no line to replace — they are what a
@@ -167,7 +180,8 @@ int pi_comm_init(pi_handle* h, int rank, int world, const void* id128);
  * through device-to-device copies ordered by HIP events — same stream semantics as RCCL. */
 int pi_comm_init_local(pi_handle* h, int rank, int world, const char* group_name);
 int pi_comm_destroy(pi_handle* h);
-/* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process), 3 plan (0 none, 1 all-gather, 2 halo). */
+/* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process), 3 plan (0 none, 1 all-gather, 2 halo),
+ * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)). */
 int pi_comm_info(pi_handle* h, int what);
 
 /* In-place collectives on the caller's stream: shard r of the buffer lives at r * shard_elems. */
@@ -178,7 +192,8 @@ int pi_allreduce_sum_u32(pi_handle* h, uint32_t* d_value, void* stream);
 
 /*
  * Pure host logic (needs no GPU and no communicator): which pieces of V' travel after a sweep.
- *   reach[r * g0 + p] != 0  <=>  rank r's shard can read dimension-0 plane p
+ *   reach[r * g0 + p] != 0  <=>  rank r's shard can read unit p, the g0 units being consecutive
+ *   runs of stride0 states (planes of dimension 0, or rows (i0, i1): pi_reach_units)
  * Writes up to `cap` segments {src, dst, a, b} ("src sends V'[a, b) to dst") and returns how many
  * there are (-1 on bad arguments).  Every rank derives the same list from the same bitmaps.
  */
@@ -186,8 +201,8 @@ int64_t pi_plan_segments(int world, int64_t g0, int64_t stride0, int64_t n_state
                          const uint8_t* reach, int64_t* segs, int64_t cap);
 
 /*
- * Collective: measure this shard's reach (pi_reach_planes, dim 0), all-gather the bitmaps, derive
- * the segments and choose the exchange.  mode 0 = choose (halo unless some rank would receive more
+ * Collective: measure this shard's reach (pi_reach_units at pi_reach_depth_max), all-gather the
+ * bitmaps, derive the segments and choose the exchange.  mode 0 = choose (halo unless some rank would receive more
  * than 60 % of an all-gather), 1 = all-gather, 2 = halo; overlap != 0 sweeps the planes peers
  * wait for first and sends them on a second stream while the interior is swept.
  * info (nullable, 5 values): mode chosen (1 | 2), elements received / sent per sweep by this rank,

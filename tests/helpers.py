@@ -130,6 +130,20 @@ class OracleSweepBackend:
             out[planes] = True
         return out
 
+    def reach_units(self, term, s_begin, s_end, depth):
+        """CPU restatement of pi_reach_units: units of the leading `depth` dimensions (planes of
+        dimension 0, rows (i0, i1)) holding any corner of any successor cell, any action."""
+        n = self.n
+        unit = int(self.strides[depth - 1])
+        out = np.zeros(n // unit, dtype=bool)
+        live = ~term.numpy()[:n][s_begin:s_end].astype(bool)
+        st = self.states[s_begin:s_end][live]
+        for a in self.actions:
+            nxt, _, done = self.lib.step(st, a)
+            idx, _ = self.lib.interp(nxt[~done], self.lo, self.hi, self.shape, self.strides)
+            out[np.unique(idx // unit)] = True
+        return out
+
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         n = self.n
         new_pol, changed = self.lib.improve_sweep(self.states, self.actions, policy.numpy()[:n],

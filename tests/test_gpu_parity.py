@@ -347,6 +347,17 @@ def test_reach_planes_matches_cpu_restatement(name, shape, cuda_device):
         got = gpu.reach_planes(d_term, a, b, int(gshape[0]))
         want = cpu.reach_planes(c_term, a, b, int(gshape[0]))
         assert np.array_equal(got, want), (name, a, b)   # planes of all 2^D corners
+        # the finer units the exchange is planned on: planes (depth 1) and rows (i0, i1) (depth 2)
+        for depth in range(1, gpu.engine.reach_depth_max() + 1):
+            got_u = gpu.reach_units(d_term, a, b, depth)
+            want_u = cpu.reach_units(c_term, a, b, depth)
+            assert np.array_equal(got_u, want_u), (name, a, b, depth)
+            if depth == 1:
+                assert np.array_equal(got_u, want)
+            else:                                        # rows refine planes: same planes, fewer values
+                rows = got_u.reshape(int(gshape[0]), int(gshape[1]))
+                assert np.array_equal(rows.any(axis=1), want)
+    assert gpu.engine.reach_depth_max() == (2 if len(shape) >= 3 else 1)
     gpu.close()
 
 
