@@ -277,7 +277,9 @@ class Engine:
         _check(lib().pi_exchange_plan(self._h, term, int(per), int(mode), int(bool(overlap)), info,
                                       stream or None), "pi_exchange_plan")
         return {"mode": "halo" if info[0] == 2 else "allgather", "recv_elems": int(info[1]),
-                "send_elems": int(info[2]), "send_ranges": int(info[3]), "interior_ranges": int(info[4])}
+                "send_elems": int(info[2]), "send_ranges": int(info[3]), "interior_ranges": int(info[4]),
+                "reach_units": {1: "planes of dimension 0", 2: "rows (i0, i1)"}.get(
+                    int(lib().pi_comm_info(self._h, 4)), "none")}
 
     def exchange_V(self, V_full, stream=0):
         _check(lib().pi_exchange_V(self._h, V_full, stream or None), "pi_exchange_V")
