@@ -144,7 +144,8 @@ def comm_unique_id() -> bytes:
 
 def plan_segments(world, g0, stride0, n_states, per, reach) -> np.ndarray:
     """Host-only planner of the halo exchange (pi_plan_segments): reach is a (world, g0) bool
-    array over g0 units of stride0 consecutive states each (planes of dimension 0, or rows (i0, i1)); returns an (m, 4) int64 array of {src, dst, a, b}."""
+    array over g0 units of stride0 consecutive states each (planes of dimension 0, or rows
+    (i0, i1)); returns an (m, 4) int64 array of {src, dst, a, b}."""
     r = np.ascontiguousarray(reach, dtype=np.uint8)
     assert r.shape == (world, g0)
     fn = lib().pi_plan_segments
