@@ -19,11 +19,14 @@
 //   improvement sweep  policy_improve_kernel :244-283 / _4d :651-691 / _6d :1081-1123
 //   max|V'-V|          cp.ReductionKernel :164-172   (fused here: no second pass)
 //   policy-stable test old.copy() / all(==) :340,:354 (fused here: changed counter)
-// One thread owns one state, as in the reference.
+// One thread owns one state, as in the reference.  Beyond the reference: a fused value-iteration
+// sweep, an LDS-resident kernel that runs whole batches of sweeps (or a whole policy evaluation)
+// of a small grid in one launch, and the reach probes the multi-GPU exchange is planned from.
 //
 // What bounds these kernels on MI355X, and what the code does about it (DESIGN.md section 4,
-// profiles/r02): the sweeps are bound by fp32 VALU *issue*, and wave64 instructions do not all
-// cost the same — v_fma/v_mul/v_add/v_and/v_xor/v_add_u32 issue in ~2.3 cycles per SIMD,
+// profiles/r02): the improvement sweep is bound by fp32 VALU *issue*, the evaluation sweep runs at
+// ~85 % of that bound and spends the rest in the L1-miss path of its divergent corner gather;
+// wave64 instructions do not all cost the same — v_fma/v_mul/v_add/v_and/v_xor/v_add_u32 issue in ~2.3 cycles per SIMD,
 // everything else (compares, selects, min/max, conversions, shifts, integer multiplies, the
 // v_div_* helpers, packed and fp64 ops) in ~4.2, transcendentals in ~8.2
 // (tools/valu_issue_bench.hip).  So:
@@ -449,12 +452,13 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
 }
 
 // ---- LDS-resident evaluation batch for small grids ----------------------------------------
-// Grids of up to PI_RESIDENT_MAX states are launch-bound: one sweep is a few microseconds of
-// launch, load -> compute -> gather latency and kernel boundary for a few thousand states of work
-// (profiles/r02/full_runs_mi355x.txt).  With a fixed policy the successor cell, its D fractional
-// offsets and the reward of a state do not change from sweep to sweep, and the whole value table
-// fits in LDS, so ONE workgroup (1024 threads in 2-D, 512 above) runs the entire batch of `n_sweeps` sweeps: the
-// dynamics once per state (results kept in registers, PI_RESIDENT_K states per thread), then per
+// Grids of a few thousand states (pi_create decides: up to 12 288 in 2-D, 4 096 in 4-D, 1 024 in
+// 6-D) are launch-bound: one sweep is a few microseconds of launch, load -> compute -> gather
+// latency and kernel boundary for very little work (profiles/r02/full_runs_mi355x.txt).  With a
+// fixed policy the successor cell, its D fractional offsets and the reward of a state do not change
+// from sweep to sweep, and the whole value table fits in LDS, so ONE workgroup (1024 threads in
+// 2-D, 512 above) runs the entire batch of `n_sweeps` sweeps: the dynamics once per state
+// (results kept in registers, PI_RESIDENT_K states per thread), then per
 // sweep 2^D LDS reads and the fmaf chain per state and two workgroup barriers (Jacobi: the new
 // values wait in registers until every lane has read the old ones).  The last two iterates go to
 // the caller's buffers exactly where the ping-pong of pi_eval_sweeps puts them (sweep i writes Vb
