@@ -148,6 +148,42 @@ def make_c1_run() -> dict:
                                                          else np.int64(v) for k, v in kw.items()})
 
 
+SMALL_RUNS = [("cartpole", (8, 8, 8, 8)), ("double_pendulum_swingup", (8, 8, 8, 8)),
+              ("double_cartpole", (4, 4, 4, 4, 4, 4))]
+
+
+def make_small_runs() -> dict:
+    """Full run()s of 4-D and 6-D envs on small grids through the reference's own kernel text (env
+    settings, at most 10 outer iterations and 5 000 sweeps per evaluation): iteration structure,
+    V and policy that the restatement must reproduce bit for bit."""
+    out = {}
+    for name, shape in SMALL_RUNS:
+        cls = envs.ENVS[name]
+        bins = env_bins(name, shape)
+        lo, hi, gshape, strides = oracle.grid_metadata(bins)
+        states = oracle.states_from_bins(bins)
+        term, tval = terminal_mask(name, states)
+        cfg = cls.CONFIG
+        kw = dict(gamma=cfg["gamma"], theta=cfg["theta"], max_eval_iter=min(cfg["max_eval_iter"], 5000),
+                  max_pi_iter=min(cfg["max_pi_iter"], 10), terminal_value=tval)
+        ref = build_ref.load(name)
+        port = oracle.build(cls._D, envs.dynamics_source(name), libm=True)
+        r = ref.run(states, cls.ACTIONS, term, lo, hi, gshape, strides, **kw)
+        p = port.run(states, cls.ACTIONS, term, lo, hi, gshape, strides, **kw)
+        assert_same(p["value_function"], r["value_function"], f"{name} run V")
+        assert_same(p["policy"], r["policy"], f"{name} run policy")
+        assert np.array_equal(p["sweeps_per_iter"], r["sweeps_per_iter"])
+        print(f"{name} {shape}: {r['outer_iterations']} outer iterations, {r['eval_sweeps']} eval sweeps, "
+              f"stable={r['stable']}, terminal states {int(term.sum())}")
+        out.update({f"{name}_shape": np.asarray(shape, np.int32), f"{name}_value_function": r["value_function"],
+                    f"{name}_policy": r["policy"], f"{name}_sweeps_per_iter": r["sweeps_per_iter"],
+                    f"{name}_outer_iterations": np.int64(r["outer_iterations"]),
+                    f"{name}_stable": np.bool_(r["stable"]),
+                    f"{name}_max_eval_iter": np.int64(kw["max_eval_iter"]),
+                    f"{name}_max_pi_iter": np.int64(kw["max_pi_iter"])})
+    return out
+
+
 def trim_reference_results() -> dict:
     out = {}
     for env in ("mountain_car", "continuous_mountain_car"):
@@ -169,6 +205,7 @@ def main() -> None:
         np.savez_compressed(OUT / f"{name}.npz", **data)
         print(f"{name:28s} ok  ({(OUT / f'{name}.npz').stat().st_size / 1024:.0f} KiB)")
     np.savez_compressed(OUT / "pendulum_c1_run.npz", **make_c1_run())
+    np.savez_compressed(OUT / "small_runs.npz", **make_small_runs())
     np.savez_compressed(OUT / "reference_results.npz", **trim_reference_results())
     total = sum(p.stat().st_size for p in OUT.glob("*.npz"))
     print(f"total {total / 1024:.0f} KiB")

@@ -93,6 +93,34 @@ def test_c1_run_reproduces_reference_text_run():
     assert np.max(np.abs(res2["value_function"] - g["value_function"])) <= 2e-6 * np.max(np.abs(g["value_function"]))  # measured 4.3e-7
 
 
+@pytest.mark.parametrize("name", ["cartpole", "double_pendulum_swingup", "double_cartpole"])
+def test_small_4d_6d_runs_reproduce_reference_text_runs(name):
+    """Full run()s of 4-D and 6-D envs (terminal states, angle wraps) on small grids, generated from
+    the reference's own kernel text (tests/golden/make_golden.py): the restatement in libm mode
+    reproduces every evaluation's sweep count, V and the policy bit for bit; the product's
+    arithmetic keeps the iteration structure and stays within 1e-5 / 99.9 %."""
+    g = np.load(H.GOLDEN / "small_runs.npz")
+    shape = tuple(int(x) for x in g[f"{name}_shape"])
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    term, tval = H.terminal_mask(name, states)
+    cfg = cls.CONFIG
+    kw = dict(gamma=cfg["gamma"], theta=cfg["theta"], max_eval_iter=int(g[f"{name}_max_eval_iter"]),
+              max_pi_iter=int(g[f"{name}_max_pi_iter"]), terminal_value=tval)
+    gV, gP = g[f"{name}_value_function"], g[f"{name}_policy"]
+    res = H.oracle_for(name, libm=True).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, **kw)
+    assert np.array_equal(res["sweeps_per_iter"], g[f"{name}_sweeps_per_iter"])
+    assert res["outer_iterations"] == int(g[f"{name}_outer_iterations"]) and res["stable"] == bool(g[f"{name}_stable"])
+    assert np.array_equal(res["policy"], gP)
+    H.assert_bits_equal(res["value_function"], gV, f"{name} V")
+    res2 = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, **kw)
+    assert res2["outer_iterations"] == int(g[f"{name}_outer_iterations"])
+    assert np.mean(res2["policy"] == gP) >= 0.999                                  # measured: 1.0, 0.9993, 1.0
+    assert np.max(np.abs(res2["value_function"] - gV)) <= 1e-5 * max(1.0, float(np.abs(gV).max()))  # measured <= 3.8e-6
+
+
 @pytest.mark.parametrize("name", ["mountain_car", "continuous_mountain_car"])
 def test_full_run_against_reference_committed_results(name):
     """The only reference-PRODUCED end-to-end numbers (runners/results/*.npz, RTX 3090 +
