@@ -156,9 +156,12 @@ class _CudaPolicyIterationBase(abc.ABC):
     """Shared implementation; the public classes fix ``_D``."""
 
     _D: int = 0
+    # Sweep backend class.  Private: the product has exactly one (the HIP backend); the CPU test-suite
+    # swaps a checker in here to exercise the host logic without a GPU (tests/helpers.py).
+    _sweep_backend_cls = None
 
     def __init__(self, bins_space: dict, action_space, config: CudaPIConfig | None = None, *,
-                 device=None, process_group=None, backend_factory=None, transport=None) -> None:
+                 device=None, process_group=None, transport=None) -> None:
         """
         bins_space   : dict with exactly D keys -> 1-D arrays of grid points (insertion order
                        = dimension order), e.g. {"theta": linspace(-pi, pi, 200), ...}
@@ -169,10 +172,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         transport    : multi-rank transport (transport.py); default: the library's RCCL transport,
                        bootstrapped over `process_group`, when torch.distributed is initialised;
                        False = stay single-rank even then
-        backend_factory : sweep-backend constructor; tests inject a CPU checker here, the
-                       product default is the HIP backend and is never replaced silently.
         """
-        if backend_factory is None and not GPU_AVAILABLE:
+        if self._sweep_backend_cls is None and not GPU_AVAILABLE:
             raise RuntimeError(
                 f"{type(self).__name__} needs libpi_mi355.so and a ROCm GPU (MI355X, gfx950): "
                 + (_native_reason() or "torch.cuda.is_available() is False"))
@@ -190,7 +191,6 @@ class _CudaPolicyIterationBase(abc.ABC):
         self._states_space = None
         self._device_arg = device
         self._process_group = process_group
-        self._backend_factory = backend_factory
         self._transport_arg = transport
         self.stats = {"eval_sweeps": 0, "improve_sweeps": 0, "pi_iterations": 0,
                       "sweeps_per_iter": [], "eval_seconds": 0.0, "improve_seconds": 0.0}
@@ -250,7 +250,7 @@ class _CudaPolicyIterationBase(abc.ABC):
     def _allocate_tensors_and_compile(self) -> None:
         import torch
         logger.info("Allocating device tensors and compiling gfx950 kernels...")
-        factory = self._backend_factory or HipSweepBackend
+        factory = self._sweep_backend_cls or HipSweepBackend
         self._backend = factory(self._D, self.grid_shape, self.bounds_low, self.bounds_high,
                                 self._bins, self.action_space, self._dynamics_cuda_src(),
                                 device=self._device_arg)
@@ -307,10 +307,7 @@ class _CudaPolicyIterationBase(abc.ABC):
             except Exception:  # noqa: BLE001
                 active = False
             if active and dist.get_world_size(self._process_group) > 1:
-                if isinstance(self._backend, HipSweepBackend):
-                    comm = T.NativeTransport.from_torch_distributed(self._process_group)
-                else:                                   # injected CPU checker (tests): test transport
-                    comm = T.TorchDistTransport(self._process_group)
+                comm = T.NativeTransport.from_torch_distributed(self._process_group)
         self._comm = comm
         self._world, self._rank = (comm.world, comm.rank) if comm is not None else (1, 0)
         self._shard_len, self._s_begin, self._s_end = T.shard_bounds(self.n_states, self._rank, self._world)

@@ -10,7 +10,8 @@ reference is imported or executed), pulls out
   * the ``_dynamics_cuda_src`` string of each runner's env class,
 
 writes both to a temporary directory and compiles oracle/ref_driver.cpp around them into
-``$TMPDIR/pi_mi355_ref/libref_<env>.so`` — OUTSIDE the repository tree, so that neither reference
+``~/.cache/pi_mi355_ref/libref_<env>_<hash of the extracted text>.so`` (a per-user directory with
+mode 0700; ``PI_MI355_REF_DIR`` overrides) — OUTSIDE the repository tree, so that neither reference
 text nor anything compiled from it can travel to the GPU box with a snapshot of the repo
 (tests/test_hygiene.py checks the tree).
 ``load(env)`` returns an ``oracle.OracleLib`` over that shared object, which
@@ -20,6 +21,8 @@ bit-for-bit against the reference's text and (b) emit the golden vectors.
 from __future__ import annotations
 
 import ast
+import hashlib
+import os
 import subprocess
 import tempfile
 from pathlib import Path
@@ -28,7 +31,7 @@ from . import OracleLib, CXX
 
 REFERENCE = Path("/root/reference")
 _HERE = Path(__file__).resolve().parent
-REF_DIR = Path(tempfile.gettempdir()) / "pi_mi355_ref"
+REF_DIR = Path(os.environ.get("PI_MI355_REF_DIR", str(Path.home() / ".cache" / "pi_mi355_ref")))
 
 # env name -> (runner file, class name, D)
 RUNNERS = {
@@ -80,18 +83,33 @@ def dynamics_text(env: str) -> str:
     return text
 
 
+def _private_dir() -> Path:
+    """REF_DIR, created 0700 and owned by this user (a shared, predictable directory would let
+    another local user pre-plant a library that load() then dlopens)."""
+    REF_DIR.mkdir(parents=True, exist_ok=True, mode=0o700)
+    st = REF_DIR.stat()
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"{REF_DIR} must belong to uid {os.getuid()} with mode 0700 "
+                           f"(found uid {st.st_uid}, mode {st.st_mode & 0o777:o})")
+    return REF_DIR
+
+
 def load(env: str, rebuild: bool = False) -> OracleLib:
     _, _, D = RUNNERS[env]
-    REF_DIR.mkdir(parents=True, exist_ok=True)
-    so = REF_DIR / f"libref_{env}.so"
+    if not available():
+        raise RuntimeError("/root/reference is not present: cannot build the reference checker")
+    dyn_text, gen_text = dynamics_text(env), generic_kernel_text(D)
+    # the file name carries a hash of everything the library is built from, so a change of the
+    # reference text (or of the driver / flags) can never be served from a stale build
+    key = hashlib.sha256("\0".join([dyn_text, gen_text, (_HERE / "ref_driver.cpp").read_text(),
+                                    " ".join(REF_CXXFLAGS)]).encode()).hexdigest()[:16]
+    so = _private_dir() / f"libref_{env}_{key}.so"
     if rebuild or not so.exists():
-        if not available():
-            raise RuntimeError("/root/reference is not present: cannot build the reference checker")
         with tempfile.TemporaryDirectory(prefix="pi_ref_") as tmp:
             dyn = Path(tmp) / "dyn.inc"
             gen = Path(tmp) / "generic.inc"
-            dyn.write_text(dynamics_text(env))
-            gen.write_text(generic_kernel_text(D))
+            dyn.write_text(dyn_text)
+            gen.write_text(gen_text)
             cmd = [CXX, *REF_CXXFLAGS, f"-DPI_D={D}", f'-DREF_DYN_FILE="{dyn}"',
                    f'-DREF_GENERIC_FILE="{gen}"', str(_HERE / "ref_driver.cpp"), "-o", str(so)]
             res = subprocess.run(cmd, capture_output=True, text=True)

@@ -25,10 +25,12 @@ BINS_SPACE = OverheadCraneCuda.bins_space(BINS_PER_DIM)
 ACTION_SPACE = OverheadCraneCuda.ACTIONS
 
 
-def train(save_path: Path = Path(DEFAULT_SAVE), **kw) -> OverheadCraneCuda:
+def train(save_path: Path = Path(DEFAULT_SAVE), target_x: float = -2.5, **kw) -> OverheadCraneCuda:
     """Policy iteration on BINS_SPACE x ACTION_SPACE with the runner's own solver settings, then
-    save (reference train(): config, construct, run(), save())."""
-    pi = OverheadCraneCuda(BINS_SPACE, ACTION_SPACE, CudaPIConfig(**OverheadCraneCuda.CONFIG), **kw)
+    save (reference train(save_path, target_x=-2.5): config, construct, run(), save() —
+    runners/overhead_crane_cuda.py:252)."""
+    pi = OverheadCraneCuda(BINS_SPACE, ACTION_SPACE, CudaPIConfig(**OverheadCraneCuda.CONFIG),
+                           target_x=target_x, **kw)
     pi.run()
     pi.save(save_path)
     return pi

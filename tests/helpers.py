@@ -82,10 +82,17 @@ def oracle_for(name: str, libm: bool = False) -> oracle.OracleLib:
     return oracle.build(envs.ENVS[name]._D, envs.dynamics_source(name), libm=libm)
 
 
+def with_checker_backend(cls):
+    """Subclass of a solver class whose sweeps run on the CPU checker below instead of the HIP
+    backend — for HOST-LOGIC tests only.  The hook is the private class attribute
+    ``_sweep_backend_cls``; the product never sets it."""
+    return type(cls.__name__ + "OnChecker", (cls,), {"_sweep_backend_cls": OracleSweepBackend})
+
+
 class OracleSweepBackend:
     """CPU stand-in for HipSweepBackend, for HOST-LOGIC tests only (run-loop semantics,
-    sharding over gloo ranks).  Lives under tests/ so the product can never pick it up; it
-    is injected explicitly through the solver's ``backend_factory`` argument."""
+    sharding over gloo ranks).  Lives under tests/ so the product can never pick it up; tests
+    install it with ``with_checker_backend``."""
 
     def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None):
         import torch

@@ -2,13 +2,13 @@
 Multi-rank host path on CPU: world_size 2, 3 and 4 over gloo.  On the GPU the exchange runs
 inside libpi_mi355.so over RCCL (csrc/pi_comm.cpp, tested with its in-process transport in
 tests/test_gpu_parity.py); here the SAME plan — the library's host-only ``pi_plan_segments`` —
-is driven from Python by the test transport (``transport.TorchDistTransport``).  Each rank
+is driven from Python by the test transport (``tests/dist_transport.py``).  Each rank
 sweeps its contiguous state shard (sizes NOT divisible by the world size, so the padded tail
 is exercised), the reachable planes (or the whole shards) travel after every evaluation sweep,
 residual / changed-count are all-reduced, and the result must be bit-identical to the
 single-rank run.  Everything a rank did not declare reachable is poisoned with
 NaN after each exchange, so a plan that misses a plane cannot pass.  The sweep backend is the
-CPU checker injected through ``backend_factory`` (test-only).
+CPU checker of tests/helpers.py (test-only hook).
 """
 from __future__ import annotations
 
@@ -39,12 +39,13 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
     from dynamicprogramming_amd import envs
     from dynamicprogramming_amd.solver import CudaPIConfig
     from tests import helpers as H
+    from tests.dist_transport import TorchDistTransport
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         cls = envs.ENVS[name]
-        s = cls(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw),
-                backend_factory=H.OracleSweepBackend)
+        s = H.with_checker_backend(cls)(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw),
+                                        transport=TorchDistTransport())
         assert s._world == world and s._rank == rank
         n = s.n_states
         per = -(-n // world)
@@ -71,8 +72,7 @@ def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, exchang
     mp.spawn(_worker, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path), exchange),
              nprocs=world, join=True)
     cls = envs.ENVS[name]
-    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw),
-                 backend_factory=H.OracleSweepBackend)
+    single = H.with_checker_backend(cls)(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw))
     single.run()
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")

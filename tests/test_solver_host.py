@@ -1,8 +1,8 @@
 """
 Host-logic tests (no GPU): the solver's run loop, batching of sweeps between residual checks,
-persistence and plugin surface, driven through the public API with the CPU checker injected
-as the sweep backend (``backend_factory=`` — test-only dependency injection; the product
-default is the HIP backend and raises without a GPU).
+persistence and plugin surface, driven through the public API with the CPU checker installed
+as the sweep backend (``tests.helpers.with_checker_backend`` — a private, test-only hook; the
+product has one backend, the HIP one, and raises without a GPU).
 """
 from __future__ import annotations
 
@@ -18,8 +18,7 @@ from tests import helpers as H
 def _solver(name, shape, config=None, **kw):
     cls = envs.ENVS[name]
     cfg = config or CudaPIConfig(**cls.CONFIG)
-    return cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg,
-               backend_factory=H.OracleSweepBackend, **kw)
+    return H.with_checker_backend(cls)(H.env_bins_space(name, shape), cls.ACTIONS, cfg, **kw)
 
 
 def _oracle_run(name, shape, cfg):
@@ -79,12 +78,11 @@ def test_plugin_surface_and_metadata():
     mask = (st[:, 0] < -2.4) | (st[:, 0] > 2.4)
     assert np.array_equal(s.d_terminal_mask[: s.n_states].numpy().astype(bool), mask)
     with pytest.raises(AssertionError, match="exactly 4"):
-        envs.CartPoleSwingUpCuda({"a": [0, 1], "b": [0, 1]}, [0.0], backend_factory=H.OracleSweepBackend)
+        H.with_checker_backend(envs.CartPoleSwingUpCuda)({"a": [0, 1], "b": [0, 1]}, [0.0])
     with pytest.raises(ValueError, match="repeated"):
-        envs.PendulumCuda({"a": [0.0, 0.0, 1.0], "b": [0.0, 1.0]}, [0.0],
-                          backend_factory=H.OracleSweepBackend)
+        H.with_checker_backend(envs.PendulumCuda)({"a": [0.0, 0.0, 1.0], "b": [0.0, 1.0]}, [0.0])
     with pytest.raises(TypeError):                      # _dynamics_cuda_src is abstract (:113)
-        CudaPolicyIteration2D({"a": [0, 1], "b": [0, 1]}, [0.0], backend_factory=H.OracleSweepBackend)
+        H.with_checker_backend(CudaPolicyIteration2D)({"a": [0, 1], "b": [0, 1]}, [0.0])
 
 
 def test_terminal_value_and_goal_seeding():
@@ -194,6 +192,10 @@ def test_runner_modules_keep_the_reference_module_surface():
         assert getattr(mod, cls.__name__) is cls
         assert mod.BINS_PER_DIM == cls.DEFAULT_BINS and list(mod.BINS_SPACE) == list(cls.bins_space(2))
         assert np.array_equal(mod.ACTION_SPACE, cls.ACTIONS) and callable(mod.train)
+    # the crane's train() solves the -2.5 m task by default, as the reference's train(save_path, target_x=-2.5)
+    import inspect
+    crane = importlib.import_module("runners.overhead_crane_cuda")
+    assert inspect.signature(crane.train).parameters["target_x"].default == -2.5
 
 
 def test_runner_loads_an_existing_archive_without_a_gpu(tmp_path, capsys):

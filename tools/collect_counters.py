@@ -11,12 +11,23 @@ import collections, csv, glob, json, os, subprocess, sys
 out = sys.argv[1]
 labels = sys.argv[2:]
 LAST = int(os.environ.get("PI_LAST", "20"))
+ENV = os.environ.get("PI_ENV", "double_pendulum_swingup")
+BINS = int(os.environ.get("PI_BINS", "80"))
 
 
 def head_hash():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from dynamicprogramming_amd import _native
     return _native.kernel_source_hash()
+
+
+def n_states():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dynamicprogramming_amd import envs
+    n = 1
+    for b in envs.ENVS[ENV].bins_space(BINS).values():
+        n *= len(b)
+    return n
 
 
 def passes(label):
@@ -67,7 +78,7 @@ cal = None
 for label in labels:
     counters, durations = passes(label)
     res = {"label": label, "kernel_source_hash": head_hash(), "dispatches_averaged": LAST,
-           "states": int(os.environ.get("PI_STATES", str(80 ** 4))),
+           "env": ENV, "bins": BINS, "states": n_states(),
            "valu_peak_measured_Ginst_per_s": measured_valu_peak(), "kernels": {}}
     for k in sorted(counters):
         c = {name: sum(v) / len(v) for name, v in counters[k].items() if v}
@@ -101,6 +112,22 @@ for label in labels:
                     e[name.lower() + "_frac_of_wave_cycles"] = c[name] / c["SQ_WAVE_CYCLES"]
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and c.get("TCP_TCC_READ_REQ_sum") is not None and c["TCP_TOTAL_CACHE_ACCESSES_sum"]:
+            e["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        gui = c.get("GRBM_GUI_ACTIVE")
+        if gui:
+            cu_cycles = gui / 8.0 * 256.0                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            e["cycles_per_launch"] = gui / 8.0
+            if e.get("ms_under_profiler"):
+                e["clock_GHz"] = gui / 8.0 / (e["ms_under_profiler"] * 1e-3) / 1e9
+            e["tcp_per_cu_cycle"] = {name: c[name] / cu_cycles for name in sorted(c)
+                                     if name.startswith("TCP_") and "LATENCY" not in name}
+            if w and "SQ_INSTS_VALU" in c:
+                e["valu_insts_per_simd_cycle"] = c["SQ_INSTS_VALU"] / (cu_cycles * 4.0)
+        if c.get("TCP_TCC_READ_REQ_LATENCY_sum") and c.get("TCP_TCC_READ_REQ_sum"):
+            e["tcp_tcc_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+        if c.get("TCP_TCP_LATENCY_sum") and c.get("TCP_TOTAL_ACCESSES_sum"):
+            e["tcp_latency_cycles_per_access"] = c["TCP_TCP_LATENCY_sum"] / c["TCP_TOTAL_ACCESSES_sum"]
         if "FETCH_SIZE" in c:
             e["FETCH_SIZE_bytes"] = c["FETCH_SIZE"] * 1024.0
         if "WRITE_SIZE" in c:
