@@ -11,10 +11,14 @@ protocol (100 evaluation + 10 improvement sweeps): 10 evaluation sweeps (fused r
 last) followed by 1 greedy improvement sweep (fused changed-count) = 10 n + 11 n = 21 n
 state-action backups, through the product path (solver -> C ABI -> HIP).
 
-N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): one process per GPU, the SAME
-grid cut into N contiguous state ranges (strong scaling); the exchange between sweeps runs
-inside libpi_mi355.so over RCCL (halo exchange of the reachable planes, or an all-gather:
-csrc/pi_comm.cpp); torch.distributed only hands the RCCL id around and times the run.
+N > 1: one process per GPU, the SAME grid cut into N contiguous state ranges (strong scaling); the
+exchange between sweeps runs inside libpi_mi355.so over RCCL (halo exchange of the reachable rows,
+or an all-gather: csrc/pi_comm.cpp); torch.distributed only hands the RCCL id around and times the
+run.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or plain
+`python bench.py --gpus N` does: it then starts exactly that command as a CHILD process (before
+anything touches the GPU; never an exec), relays rank 0's JSON line and exits with the child's
+code.  `--launch-dry-run` prints the child command instead of running it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
   roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a divergent gather plus
@@ -51,6 +55,8 @@ import argparse
 import json
 import os
 import platform
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -167,6 +173,48 @@ def load_profile(n_states: int, kernel_hash: str, label: str = "bench"):
     return None, None
 
 
+def launch_command(n_gpus: int, argv: list[str], port: int | None = None) -> list[str]:
+    """The command `python bench.py --gpus N` runs as a child when it was not started by
+    torch.distributed.run: the launch line of the bench contract, one rank per GPU on this node."""
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    rest = [a for a in argv if a != "--launch-dry-run"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + rest
+
+
+def self_launch(n_gpus: int, argv: list[str], dry_run: bool) -> int:
+    """Start the ranks as a child process (never exec: nothing here has touched the GPU, and nothing
+    will), pass their stderr through, relay rank 0's one JSON line, return the child's exit code
+    (non-zero when any rank failed or no line was printed)."""
+    cmd = launch_command(n_gpus, argv)
+    if dry_run:
+        print(json.dumps({"launch": cmd, "note": "dry run: the ranks were not started"}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for cand in proc.stdout.splitlines():
+        try:
+            obj = json.loads(cand)
+        except ValueError:
+            continue
+        if isinstance(obj, dict) and "metric" in obj:
+            line = cand
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        print(f"bench.py: the {n_gpus}-rank child exited with code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +235,16 @@ def main() -> None:
                     help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
                          "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
                          "the 1-thread run takes every 16th of those)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="with --gpus N > 1 outside torch.distributed.run: print the child command that "
+                         "would start the N ranks, and exit")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # started by torch.distributed.run
+    if not launched and (args.gpus > 1 or args.launch_dry_run):
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_dry_run))
 
     import torch
     import torch.distributed as dist
@@ -197,7 +254,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -403,7 +460,23 @@ def main() -> None:
 
     exchange = None
     if solver._comm is not None and getattr(solver._comm, "info", None):
-        exchange = solver._comm.info
+        # what the driver needs to see that RCCL really ran with N ranks: the communicator's own view
+        # (pi_comm_info), this rank's plan, and every rank's evaluation time and halo volume
+        exchange = dict(solver._comm.info)
+        exchange["world"] = eng.comm_info(1)
+        exchange["transport"] = {1: "rccl", 2: "in-process"}.get(eng.comm_info(2), "none")
+        exchange["comm_rank"] = eng.comm_info(0)
+        mine = torch.tensor([eval_ms, improve_ms, float(exchange["recv_elems"]), float(exchange["send_elems"]),
+                             float(states_per_launch)], dtype=torch.float64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        table = torch.stack(everyone).cpu().numpy()
+        exchange["per_rank"] = {"eval_ms": table[:, 0].tolist(), "improve_ms": table[:, 1].tolist(),
+                                "bytes_received_per_sweep": (table[:, 2] * 4).astype(np.int64).tolist(),
+                                "bytes_sent_per_sweep": (table[:, 3] * 4).astype(np.int64).tolist(),
+                                "states": table[:, 4].astype(np.int64).tolist()}
+        exchange["eval_ms_max"], exchange["eval_ms_min"] = float(table[:, 0].max()), float(table[:, 0].min())
+        exchange["bytes_received_per_sweep_max"] = int(table[:, 2].max() * 4)
     out = {
         "metric": "state-action Bellman backups/sec",
         "value": value,

@@ -22,7 +22,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -54,6 +56,7 @@ struct ShardPlan {
     std::vector<Seg> segs;                                   // only those that involve this rank
     std::vector<std::pair<int64_t, int64_t>> send_ranges, interior;
     int64_t recv_elems = 0, send_elems = 0;
+    bool broken = false;            // a sharded sweep failed half-way: streams were drained, plan again
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     ~ShardPlan() {
@@ -84,35 +87,85 @@ namespace {
             return fail(std::string(#expr) + ": " + ncclGetErrorString(r_));               \
     } while (0)
 
+// How long a rank waits for a peer before it declares the exchange dead (seconds).  The RCCL
+// transport has its own watchdog-free wait on the GPU; what is bounded here are the HOST waits of the
+// in-process transport and the host-side polls for an asynchronous RCCL error.
+double comm_timeout_seconds() {
+    if (const char* e = std::getenv("PI_MI355_COMM_TIMEOUT")) {
+        const double v = std::atof(e);
+        if (v > 0.0) return v;
+    }
+    return 120.0;
+}
+
 // ---- RCCL ------------------------------------------------------------------------------
+// Failure handling ("RCCL error -> abort with message"): every RCCL call goes
+// through check(); on the first error an open group is closed (a group left open would swallow
+// every later call of the thread), the communicator is aborted (ncclCommAbort frees the peers'
+// resources and unblocks kernels that wait for this rank) and the handle refuses further
+// collectives with the recorded message.  After every group / collective the communicator's
+// asynchronous error state is polled once (ncclCommGetAsyncError): a peer that died shows up there.
 struct RcclComm : pi::Comm {
     ncclComm_t comm = nullptr;
+    bool in_group = false;
+    std::string dead;                       // non-empty once the communicator has been aborted
     ~RcclComm() override {
         if (comm) (void)ncclCommDestroy(comm);
     }
     const char* kind() const override { return "rccl"; }
-    int group_begin() override { PI_NCCL(ncclGroupStart()); return 0; }
-    int send(const void* p, size_t bytes, int peer, hipStream_t st) override {
-        PI_NCCL(ncclSend(p, bytes, ncclChar, peer, comm, st));
+    int abort_with(const std::string& why) {
+        if (in_group) { (void)ncclGroupEnd(); in_group = false; }
+        if (comm) { (void)ncclCommAbort(comm); comm = nullptr; }
+        dead = "RCCL communicator aborted (rank " + std::to_string(rank) + " of " + std::to_string(world) + "): " + why;
+        return fail(dead);
+    }
+    int check(ncclResult_t r, const char* what) {
+        if (r == ncclSuccess) return 0;
+        return abort_with(std::string(what) + ": " + ncclGetErrorString(r));
+    }
+    int alive() { return dead.empty() && comm ? 0 : fail(dead.empty() ? "no RCCL communicator" : dead); }
+    int poll_async() {
+        ncclResult_t st = ncclSuccess;
+        if (check(ncclCommGetAsyncError(comm, &st), "ncclCommGetAsyncError")) return 1;
+        if (st != ncclSuccess && st != ncclInProgress)
+            return abort_with(std::string("asynchronous error: ") + ncclGetErrorString(st));
         return 0;
+    }
+    int group_begin() override {
+        if (alive()) return 1;
+        if (check(ncclGroupStart(), "ncclGroupStart")) return 1;
+        in_group = true;
+        return 0;
+    }
+    int send(const void* p, size_t bytes, int peer, hipStream_t st) override {
+        if (alive()) return 1;
+        return check(ncclSend(p, bytes, ncclChar, peer, comm, st), "ncclSend");
     }
     int recv(void* p, size_t bytes, int peer, hipStream_t st) override {
-        PI_NCCL(ncclRecv(p, bytes, ncclChar, peer, comm, st));
-        return 0;
+        if (alive()) return 1;
+        return check(ncclRecv(p, bytes, ncclChar, peer, comm, st), "ncclRecv");
     }
-    int group_end(hipStream_t) override { PI_NCCL(ncclGroupEnd()); return 0; }
+    int group_end(hipStream_t) override {
+        if (alive()) return 1;
+        in_group = false;
+        if (check(ncclGroupEnd(), "ncclGroupEnd")) return 1;
+        return poll_async();
+    }
     int allgather(void* full, size_t bytes, hipStream_t st) override {
-        PI_NCCL(ncclAllGather(static_cast<const char*>(full) + (size_t)rank * bytes, full, bytes, ncclChar,
-                              comm, st));
-        return 0;
+        if (alive()) return 1;
+        if (check(ncclAllGather(static_cast<const char*>(full) + (size_t)rank * bytes, full, bytes, ncclChar,
+                                comm, st), "ncclAllGather")) return 1;
+        return poll_async();
     }
     int allreduce_max_f32(float* d, hipStream_t st) override {
-        PI_NCCL(ncclAllReduce(d, d, 1, ncclFloat, ncclMax, comm, st));
-        return 0;
+        if (alive()) return 1;
+        if (check(ncclAllReduce(d, d, 1, ncclFloat, ncclMax, comm, st), "ncclAllReduce(max)")) return 1;
+        return poll_async();
     }
     int allreduce_sum_u32(uint32_t* d, hipStream_t st) override {
-        PI_NCCL(ncclAllReduce(d, d, 1, ncclUint32, ncclSum, comm, st));
-        return 0;
+        if (alive()) return 1;
+        if (check(ncclAllReduce(d, d, 1, ncclUint32, ncclSum, comm, st), "ncclAllReduce(sum)")) return 1;
+        return poll_async();
     }
 };
 
@@ -127,6 +180,7 @@ struct LocalGroup {
     std::mutex mu;
     std::condition_variable cv;
     int world = 0, joined = 0, left = 0;
+    bool failed = false;                                     // a member gave up: nobody waits any longer
     struct Msg {
         const void* src = nullptr;
         size_t bytes = 0;
@@ -162,6 +216,23 @@ struct LocalComm : pi::Comm {
         if (grp && ++grp->left == grp->world) g_groups.erase(name);
     }
     const char* kind() const override { return "local"; }
+    // Every host wait of this transport is bounded: a peer that failed (or never arrives) turns into
+    // an error on all members after PI_MI355_COMM_TIMEOUT seconds instead of a hang.
+    template <typename Pred>
+    int wait_for(std::unique_lock<std::mutex>& lk, Pred ready, const char* what) {
+        const auto limit = std::chrono::duration<double>(comm_timeout_seconds());
+        if (!grp->cv.wait_for(lk, limit, [&] { return grp->failed || ready(); }) || grp->failed) {
+            grp->failed = true;
+            grp->cv.notify_all();
+            return fail(std::string("local transport: rank ") + std::to_string(rank) + " gave up waiting for " + what);
+        }
+        return 0;
+    }
+    void give_up() {
+        std::lock_guard<std::mutex> lk(grp->mu);
+        grp->failed = true;
+        grp->cv.notify_all();
+    }
     int group_begin() override { return 0; }
     int send(const void* p, size_t bytes, int peer, hipStream_t st) override {
         auto m = std::make_shared<LocalGroup::Msg>();
@@ -188,11 +259,15 @@ struct LocalComm : pi::Comm {
             {
                 std::unique_lock<std::mutex> lk(grp->mu);
                 auto& q = grp->box[(size_t)r.peer * world + rank];
-                grp->cv.wait(lk, [&] { return !q.empty(); });
+                if (wait_for(lk, [&] { return !q.empty(); }, "a send of its peer")) { recvs.clear(); return 1; }
                 m = q.front();
                 q.pop_front();
             }
-            if (m->bytes != r.bytes) return fail("local transport: send/recv size mismatch");
+            if (m->bytes != r.bytes) {
+                give_up();
+                recvs.clear();
+                return fail("local transport: send/recv size mismatch");
+            }
             PI_HIP(hipStreamWaitEvent(r.st, m->ready, 0));
             PI_HIP(hipMemcpyAsync(r.p, m->src, r.bytes, hipMemcpyDeviceToDevice, r.st));
             PI_HIP(hipEventRecord(m->done, r.st));
@@ -206,7 +281,7 @@ struct LocalComm : pi::Comm {
         for (auto& m : sent) {
             {
                 std::unique_lock<std::mutex> lk(grp->mu);
-                grp->cv.wait(lk, [&] { return m->copied; });
+                if (wait_for(lk, [&] { return m->copied; }, "its peer to receive")) return 1;
             }
             PI_HIP(hipStreamWaitEvent(st, m->done, 0));
         }
@@ -240,8 +315,8 @@ struct LocalComm : pi::Comm {
             grp->red.clear();
             ++grp->red_epoch;
             grp->cv.notify_all();
-        } else {
-            grp->cv.wait(lk, [&] { return grp->red_epoch != epoch; });
+        } else if (wait_for(lk, [&] { return grp->red_epoch != epoch; }, "the other ranks of a reduction")) {
+            return 1;
         }
         *out = grp->red_result;
         return 0;
@@ -251,7 +326,7 @@ struct LocalComm : pi::Comm {
         PI_HIP(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, st));
         PI_HIP(hipStreamSynchronize(st));
         double r;
-        reduce_host((double)v, true, &r);
+        if (reduce_host((double)v, true, &r)) return 1;
         v = (float)r;
         PI_HIP(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st));
         PI_HIP(hipStreamSynchronize(st));
@@ -262,7 +337,7 @@ struct LocalComm : pi::Comm {
         PI_HIP(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, st));
         PI_HIP(hipStreamSynchronize(st));
         double r;
-        reduce_host((double)v, false, &r);
+        if (reduce_host((double)v, false, &r)) return 1;
         v = (uint32_t)r;
         PI_HIP(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, st));
         PI_HIP(hipStreamSynchronize(st));
@@ -278,6 +353,9 @@ int need_comm(pi_handle* h) {
 int need_plan(pi_handle* h) {
     if (need_comm(h)) return 1;
     if (!h->plan) return fail("no exchange plan on this handle: call pi_exchange_plan first");
+    if (h->plan->broken)
+        return fail("a sharded sweep failed on this handle and its exchange was abandoned: call pi_exchange_plan again "
+                    "(all ranks) before the next sharded sweep");
     return 0;
 }
 
@@ -288,8 +366,12 @@ int post_exchange(pi_handle* h, float* full, hipStream_t st) {
     if (c->group_begin()) return 1;
     for (const auto& s : p->segs) {
         const size_t bytes = (size_t)(s.b - s.a) * sizeof(float);
-        if (s.src == c->rank) { if (c->send(full + s.a, bytes, s.dst, st)) return 1; }
-        else if (c->recv(full + s.a, bytes, s.src, st)) return 1;
+        const int rc = s.src == c->rank ? c->send(full + s.a, bytes, s.dst, st) : c->recv(full + s.a, bytes, s.src, st);
+        if (rc) {                       // the transport has closed its group (RCCL: and aborted); keep its message
+            const std::string why = pi::last_error();
+            (void)c->group_end(st);
+            return fail(why);
+        }
     }
     return c->group_end(st);
 }
@@ -504,7 +586,11 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
         // dimension 0 (at least 2^16 states) apart become ONE launch, so a shard is still swept
         // in about three launches (low boundary planes, high boundary planes, interior) although
         // the segments that travel are single rows.
-        const int64_t gap = std::max<int64_t>(int64_t(1) << 16, 2 * (n / h->shape[0]));
+        // The gap is bounded by an eighth of the shard: with shards of ~10 planes (C4 at 8 ranks) two
+        // planes would merge every send range into the whole shard and leave nothing to sweep while
+        // the halo travels (profiles/r02/halo_granularity.txt: "1 / 0").
+        const int64_t gap = std::min(std::max<int64_t>(int64_t(1) << 16, 2 * (n / h->shape[0])),
+                                     std::max<int64_t>((plan->s_end - plan->s_begin) / 8, 1));
         for (const auto& r : cuts) {
             if (!plan->send_ranges.empty() && r.first <= plan->send_ranges.back().second + gap)
                 plan->send_ranges.back().second = std::max(plan->send_ranges.back().second, r.second);
@@ -566,31 +652,46 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
     hipStream_t st = (hipStream_t)stream;
     pi::ShardPlan* p = h->plan;
     const bool overlap = p->halo && p->comm_stream != nullptr;
-    for (int k = 0; k < n_sweeps; ++k) {
-        const float* src = (k & 1) ? Vb : Va;
-        float* dst = (k & 1) ? Va : Vb;
-        const bool want = k == n_sweeps - 1 && d_delta != nullptr;
-        if (overlap) {
-            for (const auto& r : p->send_ranges)
-                if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
-            PI_HIP(hipEventRecord(p->ev_ready, st));
-            PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
-            if (post_exchange(h, dst, p->comm_stream)) return 1;
-            PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
-            for (const auto& r : p->interior)
-                if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
-            PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
-        } else {
-            if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st)) return 1;
-            if (pi_exchange_V(h, dst, stream)) return 1;
+    auto batch = [&]() -> int {
+        for (int k = 0; k < n_sweeps; ++k) {
+            const float* src = (k & 1) ? Vb : Va;
+            float* dst = (k & 1) ? Va : Vb;
+            const bool want = k == n_sweeps - 1 && d_delta != nullptr;
+            if (overlap) {
+                for (const auto& r : p->send_ranges)
+                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+                PI_HIP(hipEventRecord(p->ev_ready, st));
+                PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
+                if (post_exchange(h, dst, p->comm_stream)) return 1;
+                PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
+                for (const auto& r : p->interior)
+                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+                PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
+            } else {
+                if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st)) return 1;
+                if (pi_exchange_V(h, dst, stream)) return 1;
+            }
         }
-    }
-    if (d_delta) {
-        if (p->s_end == p->s_begin) PI_HIP(hipMemsetAsync(d_delta, 0, sizeof(float), st));
-        else if (pi::finalize(h, d_delta, nullptr, st)) return 1;
-        return h->comm->allreduce_max_f32(d_delta, st);
-    }
-    return 0;
+        if (d_delta) {
+            if (p->s_end == p->s_begin) PI_HIP(hipMemsetAsync(d_delta, 0, sizeof(float), st));
+            else if (pi::finalize(h, d_delta, nullptr, st)) return 1;
+            return h->comm->allreduce_max_f32(d_delta, st);
+        }
+        return 0;
+    };
+    if (batch() == 0) return 0;
+    // Failure half-way through the batch: leave a DEFINED state behind.  Drain both streams (a
+    // launch or an event may be pending on either), clear the residual slots a finished sweep may
+    // have filled, and retire the plan — the peers are at an unknown sweep, so the next sharded call
+    // must be preceded by a collective pi_exchange_plan.  The error of the failing call is kept.
+    const std::string why = pi::last_error();
+    if (auto* local = dynamic_cast<LocalComm*>(h->comm)) local->give_up();   // in-process peers stop waiting at once
+    if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemsetAsync(h->d_slots, 0, 2 * pi::kSlots * sizeof(unsigned int), st);
+    (void)hipGetLastError();
+    p->broken = true;
+    return fail("pi_eval_sweeps_sharded abandoned (streams drained, exchange plan retired): " + why);
 }
 
 // Greedy improvement of this rank's shard; d_changed (nullable) = entries changed, summed over ranks.

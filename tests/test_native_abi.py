@@ -109,9 +109,28 @@ def test_argument_validation():
     with pytest.raises(_native.NativeError, match="2\\^31"):
         big = [np.linspace(0, 1, 40, dtype=np.float32)] * 6
         _native.Engine(6, [40] * 6, [0] * 6, [1] * 6, big, [0.0], device=-1)
+    # the guard sits exactly at 2^31 states (flat indices are int32, as in the reference)
+    edge = [np.linspace(0, 1, g, dtype=np.float32) for g in (256, 256, 256, 128)]
+    with pytest.raises(_native.NativeError, match="2\\^31"):
+        _native.Engine(4, [256, 256, 256, 128], [0] * 4, [1] * 4, edge, [0.0], device=-1)
+    edge[3] = np.linspace(0, 1, 127, dtype=np.float32)
+    ok = _native.Engine(4, [256, 256, 256, 127], [0] * 4, [1] * 4, edge, [0.0], device=-1)
+    assert ok.n_states == 256 ** 3 * 127 < 2 ** 31
+    ok.close()
     eng = _host_engine("pendulum", (8, 8))
     with pytest.raises(_native.NativeError, match="host-only"):
         eng.eval_sweep(1, 2, 3, 4, 0, 64, 0.9)
+    eng.close()
+
+
+def test_grids_beyond_32_bit_byte_offsets_compile(tmp_path):
+    """n >= 2^30 states: 4 n no longer fits a 32-bit byte offset, the template switches to 64-bit
+    element addressing (PI_OFF32 == false); it has to build for gfx950 like the 32-bit form
+    (run on hardware by tests/test_gpu_endtoend.py::test_64_bit_addressing_path_at_2_pow_30_states)."""
+    eng = _host_engine("double_cartpole", (32,) * 6)
+    assert eng.n_states == 1 << 30
+    eng.compile(envs.dynamics_source("double_cartpole"), cache_dir=tmp_path)
+    assert eng.info(7) == 0 and len(list(tmp_path.glob("pi_*.hsaco"))) == 1
     eng.close()
 
 

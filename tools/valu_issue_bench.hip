@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -73,6 +74,36 @@ __device__ float pi_fold(f2 v) { return v.x + v.y; }
         unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                          \
         float res = pi_fold(a0) + pi_fold(a1) + pi_fold(a2) + pi_fold(a3) + pi_fold(a4) +  \
                     pi_fold(a5) + pi_fold(a6) + pi_fold(a7);                               \
+        if ((threadIdx.x & 63) == 0) {                                                     \
+            unsigned int hw, xcc;                                                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));               \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));             \
+            Stamp s = {t0, t1, r0, r1, hw, xcc};                                           \
+            out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;                         \
+        }                                                                                  \
+        if (res == 12345.678f) sink[0] = res;                                              \
+    }
+
+// Same kernel with a loop body of 64 hand-laid instructions (no inner repetition): the mixed and
+// clustered streams below need more than 8 slots per period.
+#define DEFINE_BENCH64(NAME, BODY)                                                         \
+    __global__ void __launch_bounds__(256) NAME(Stamp* out, float* sink, int iters) {      \
+        float a0 = pi_seed<float>(0), a1 = pi_seed<float>(1), a2 = pi_seed<float>(2),      \
+              a3 = pi_seed<float>(3), a4 = pi_seed<float>(4), a5 = pi_seed<float>(5),      \
+              a6 = pi_seed<float>(6), a7 = pi_seed<float>(7);                              \
+        float x = pi_seed<float>(9), y = pi_seed<float>(11);                               \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                              \
+        unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                          \
+        for (int i = 0; i < iters; ++i) {                                                  \
+            asm volatile(BODY                                                              \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),     \
+                           "+v"(a6), "+v"(a7)                                              \
+                         : "v"(x), "v"(y)                                                  \
+                         : "vcc", "s40", "s41");                                           \
+        }                                                                                  \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                              \
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                          \
+        float res = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                 \
         if ((threadIdx.x & 63) == 0) {                                                     \
             unsigned int hw, xcc;                                                          \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));               \
@@ -153,6 +184,38 @@ DEFINE_BENCH(bench_mix_fma_snop, float,
              PI_I(4, "v_fma_f32 ", ", %8, %9, ", "") "s_nop 0\n\t"
              PI_I(6, "v_fma_f32 ", ", %8, %9, ", "") "s_nop 0\n\t")
 
+// ---- mixed and clustered streams ----------------------------------------------
+// Does an "other"-class instruction (4.15 cycles alone) hide under fp32 fma-class ones (2.3 cycles) only
+// when the two classes ALTERNATE, or also at the sweep kernels' real ratio and when each class comes
+// in runs, as compiled code has them (cell search: compares/conversions/selects in a row; corner
+// weights and the fmaf chain: multiplies and fmas in a row)?  F = v_fma_f32, O = v_max_f32,
+// P = v_cmp + v_cndmask pair (2 other-class instructions), C = v_cvt_i32_f32, T = v_rcp_f32; eight
+// independent accumulators, cycled, so every stream has the same instruction-level parallelism.
+#define F_(k) "v_fma_f32 %" #k ", %8, %9, %" #k "\n\t"
+#define O_(k) "v_max_f32 %" #k ", %8, %" #k "\n\t"
+#define C_(k) "v_cvt_i32_f32 %" #k ", %" #k "\n\t"
+#define T_(k) "v_rcp_f32 %" #k ", %" #k "\n\t"
+#define F8 F_(0) F_(1) F_(2) F_(3) F_(4) F_(5) F_(6) F_(7)
+#define O8 O_(0) O_(1) O_(2) O_(3) O_(4) O_(5) O_(6) O_(7)
+#define C8 C_(0) C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7)
+#define FFO8 F_(0) F_(1) O_(2) F_(3) F_(4) O_(5) F_(6) F_(7)        /* 6 F + 2 O */
+#define FFO8b O_(0) F_(1) F_(2) O_(3) F_(4) F_(5) O_(6) F_(7)       /* 5 F + 3 O */
+// 2:1 like the evaluation sweep (539 fma-class : 257 other : 9 transcendental per wave), interleaved F F O
+DEFINE_BENCH64(bench_ratio21_interleaved, FFO8 FFO8b FFO8 FFO8b FFO8 FFO8b FFO8 FFO8b)          // 44 F + 20 O
+// the same 44 : 20, each class in one run
+DEFINE_BENCH64(bench_ratio21_one_run, F8 F8 F8 F8 F8 F_(0) F_(1) F_(2) F_(3) O_(4) O_(5) O_(6) O_(7) O8 O8)
+// the same 44 : 20 in runs of 8 other-class instructions: 16 F 8 O 16 F 8 O 12 F 4 O
+DEFINE_BENCH64(bench_ratio21_runs8, F8 F8 O8 F8 F8 O8 F8 F_(0) F_(1) F_(2) F_(3) O_(4) O_(5) O_(6) O_(7))
+// 1:1 in runs of 8 / 16 / 32 (the alternating row above is runs of 1)
+DEFINE_BENCH64(bench_half_runs8, F8 O8 F8 O8 F8 O8 F8 O8)
+DEFINE_BENCH64(bench_half_runs16, F8 F8 O8 O8 F8 F8 O8 O8)
+DEFINE_BENCH64(bench_half_runs32, F8 F8 F8 F8 O8 O8 O8 O8)
+// 2:1 with the other class made of conversions instead of max
+DEFINE_BENCH64(bench_ratio21_cvt_runs8, F8 F8 C8 F8 F8 C8 F8 F_(0) F_(1) F_(2) F_(3) C_(4) C_(5) C_(6) C_(7))
+// the evaluation sweep's mix with its transcendentals: 43 F + 20 O + 1 T, interleaved
+DEFINE_BENCH64(bench_ratio_eval_interleaved,
+               FFO8 FFO8b FFO8 FFO8b FFO8 FFO8b FFO8 O_(0) F_(1) F_(2) O_(3) F_(4) F_(5) O_(6) T_(7))
+
 struct Row {
     const char* name;
     void (*fn)(Stamp*, float*, int);
@@ -175,7 +238,15 @@ int main(int argc, char** argv) {
                         {"mix fma,max alternating", bench_mix_fma_max},
                         {"mix fma,s_nop alternating", bench_mix_fma_snop},
                         {"pair v_cmp+v_cndmask (vcc)", bench_pair_cmp_cndmask},
-                        {"pair v_cmp+v_cndmask (sgpr)", bench_pair_cmp_cndmask_sgpr}};
+                        {"pair v_cmp+v_cndmask (sgpr)", bench_pair_cmp_cndmask_sgpr},
+                        {"44 fma : 20 max, interleaved", bench_ratio21_interleaved},
+                        {"44 fma : 20 max, runs of 8 max", bench_ratio21_runs8},
+                        {"44 fma : 20 max, one run each", bench_ratio21_one_run},
+                        {"44 fma : 20 cvt, runs of 8 cvt", bench_ratio21_cvt_runs8},
+                        {"43 fma : 20 max : 1 rcp, interl.", bench_ratio_eval_interleaved},
+                        {"32 fma : 32 max, runs of 8", bench_half_runs8},
+                        {"32 fma : 32 max, runs of 16", bench_half_runs16},
+                        {"32 fma : 32 max, runs of 32", bench_half_runs32}};
     float* sink;
     CHECK(hipMalloc((void**)&sink, 4));
     hipEvent_t e0, e1;
@@ -183,7 +254,9 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e1));
     std::printf("%-32s %9s %6s %14s %12s %12s %10s\n", "instruction", "blocks/CU", "share",
                 "cyc/instr(wave)", "cyc/instr(SIMD)", "chip Ginstr/s", "clock GHz");
+    const char* only = argc > 2 ? argv[2] : nullptr;        // optional: run only the rows whose name contains this
     for (const Row& row : rows) {
+        if (only && !std::strstr(row.name, only)) continue;
         for (int per_cu : {1, 2, 4, 8}) {
             const int blocks = cus * per_cu, waves = blocks * 4;
             Stamp* d;
