@@ -21,24 +21,26 @@ anything touches the GPU; never an exec), relays rank 0's JSON line and exits wi
 code.  `--launch-dry-run` prints the child command instead of running it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
-  roofline      — dominant kernel = pi_eval_sweep_kernel.  These sweeps are a divergent gather plus
-                  ~400 fp32 VALU instructions of dynamics per state; HBM is not what bounds them
-                  (27 % of 8 TB/s, `hbm_frac`).  The hard on-chip ceiling is fp32 VALU ISSUE:
-                  achieved = SIMD issue-cycles delivered per second = (instructions per wave by
-                  class, from the committed PMC profile of THIS kernel version) x (cycles per wave64
-                  instruction of that class, measured by tools/valu_issue_bench.hip: 2.3 fp32
-                  fma/mul/add, 4.15 other, 8.15 transcendental) x waves per launch / mean launch time
-                  (HIP events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz = 2457.6 G
-                  SIMD-cycles/s; frac = achieved / peak = the time the instruction mix needs at the
-                  NOMINAL clock over the time the launch took (the chip holds ~2.0-2.1 GHz under this
-                  load: clock_GHz_under_profiler).
-                  `l1_gather_model` says what the rest of the time is: the vector-L1 (TCP) path of
-                  the corner gather — line accesses + 1.23 cycles per line that L2 has to serve
-                  (tools/tcp_gather_bench.hip, profiles/r02/tcp_gather.txt, l1_path_counters.txt),
-                  as a share of the launch time.  It is a model that reproduces the time, not a
-                  peak (the improvement sweep pushes more accesses per cycle through the same unit).
-                  traffic = HBM-side bytes per launch from the same profile (FETCH_SIZE x 2 on
-                  gfx950 + WRITE_SIZE), withheld when the profile is of another kernel version.
+  roofline      — dominant kernel of the step (pi_eval_sweep_kernel in every BASELINE config).  These sweeps
+                  are a divergent gather plus 300-600 fp32 VALU instructions of dynamics per state; the
+                  committed PMC profile of THIS kernel version and THIS config (profiles/rNN/
+                  counters_bench_<config>.json, matched on env, bins and the hash of the device code) gives
+                  the work per launch, the launch time is measured live (HIP events on the launch stream),
+                  and three units are priced, each against its hardware peak:
+                    valu  wave64 VALU instructions/s against 1228.8 G/s (MI355X_MICROARCH.md: a wave64
+                          fp32 instruction per 2 cycles per SIMD x 1024 SIMDs x 2.4 GHz).  The chip measures
+                          ~950 G/s for fp32 fma/mul/add streams AND for mixes with compares / selects /
+                          conversions up to 1:1, clustered or not (tools/valu_issue_bench.hip,
+                          profiles/r03/valu_issue.txt) — round 2's additive per-class model is withdrawn;
+                    l1    vector-L1 (TCP) tag look-ups/s (TCP_TOTAL_CACHE_ACCESSES) against one look-up per
+                          CU and cycle = 614.4 G/s: a wave-wide 8-byte load costs max(16, lines touched)
+                          look-ups (tools/tcp_gather_bench.hip), so 2^(D-1) corner-pair loads per state put
+                          a floor of 16 x 2^(D-1) look-ups under every wave — 512 per 64 states in 6-D;
+                    hbm   HBM-side bytes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) against 8 TB/s.
+                  `bound` names the unit with the highest utilisation, `achieved` / `peak` / `frac` are
+                  that unit's; `units` carries all three; `traffic` = the HBM-side bytes per launch.
+                  Everything that comes from the profile is withheld (null) when no committed profile
+                  matches the config and the kernel version.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
                   launch time, for reference only: those bytes are cache hits, not a bound.
   sweeps_to_converge — a full run() of policy iteration from V = 0 with the env's own settings (N = 1,
@@ -69,8 +71,8 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0     # wave64 fp32 VALU instructions/s: 2 cycles each per SIMD-32
-SIMD_PEAK_GCYC = 256 * 4 * 2.4           # SIMD issue-cycles per second at the nominal 2.4 GHz
-TCP_PEAK_GCYC = 256 * 2.4                # vector-L1 (TCP) cycles per second: one line look-up per CU and cycle
+VALU_MEASURED_GIPS = 950.0               # what the chip sustains for fp32 and mixed streams (profiles/r03/valu_issue.txt)
+TCP_PEAK_GCYC = 256 * 2.4                # vector-L1 (TCP) tag look-ups per second: one per CU and cycle
 TCP_CYCLES_PER_L2_LINE = 1.23            # extra TCP cycles per TCP->TCC request (profiles/r02/tcp_gather.txt)
 ENV = "double_pendulum_swingup"
 BINS = 80
@@ -160,15 +162,17 @@ def numpy_reference_c1() -> dict:
             "config": "Pendulum 50 x 50 x 11 actions, numpy float32, one thread"}
 
 
-def load_profile(n_states: int, kernel_hash: str, label: str = "bench"):
-    """Latest committed PMC profile of the bench (or policy-iteration: label "real") state whose
-    kernel hash is the current one."""
-    for path in sorted(ROOT.glob(f"profiles/r*/counters_{label}_c4.json"), reverse=True):
+def load_profile(env: str, bins: int, n_states: int, kernel_hash: str, label: str = "bench"):
+    """Latest committed PMC profile (tools/profile_config.sh) of this config — env, bins — on the bench
+    (or policy-iteration: label "real") state whose kernel hash is the current one."""
+    for path in sorted(ROOT.glob(f"profiles/r*/counters_{label}_*.json"), reverse=True):
         try:
             prof = json.loads(path.read_text())
         except (OSError, ValueError):
             continue
-        if prof.get("kernel_source_hash") == kernel_hash and prof.get("states", n_states) == n_states:
+        if prof.get("kernel_source_hash") != kernel_hash or prof.get("states", n_states) != n_states:
+            continue
+        if prof.get("env", ENV) == env and prof.get("bins", BINS) == bins:
             return prof, str(path.relative_to(ROOT))
     return None, None
 
@@ -365,93 +369,84 @@ def main() -> None:
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
-    prof, prof_path = load_profile(n, khash) if (world == 1 and args.env == ENV and args.bins == BINS) else (None, None)
+    prof, prof_path = load_profile(args.env, args.bins, n, khash) if world == 1 else (None, None)
     bytes_eval = algorithmic_bytes_eval(D)
     bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
     compulsory = 13.0 * states_per_launch       # V read + V' write + policy + mask, cache-perfect
 
-    def kernel_entry(name, ms, backups, alg_bytes_per_backup, l1_model=False):
-        e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups,
-             "backups_per_s": backups / (ms * 1e-3)}
-        alg = alg_bytes_per_backup * backups / (ms * 1e-3) / 1e9
+    def kernel_entry(name, ms, backups, alg_bytes_per_backup, counters=None):
+        """Timing of one kernel plus, when a matching profile exists, the utilisation of the three
+        units it can be bound by (VALU issue, vector-L1 tag look-ups, HBM)."""
+        sec = ms * 1e-3
+        e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups, "backups_per_s": backups / sec}
+        alg = alg_bytes_per_backup * backups / sec / 1e9
         e["algorithmic"] = {"bytes_per_backup": alg_bytes_per_backup, "achieved_GBps": alg,
                             "note": "SURVEY 8(d) byte model; served by L1/L2/Infinity Cache, not a bound"}
-        k = (prof or {}).get("kernels", {}).get(name)
-        if k and "valu_insts_per_wave" in k:
-            waves = k["counters"]["SQ_WAVES"]
-            insts = k["valu_insts_per_wave"] * waves
-            ach = insts / (ms * 1e-3) / 1e9
-            e["valu"] = {"insts_per_wave": k["valu_insts_per_wave"], "waves_per_launch": waves,
-                         "achieved_Ginst_per_s": ach, "inst_rate_frac_of_peak": ach / VALU_PEAK_GIPS,
-                         "issue_cycles_model": k.get("issue_cycles_model")}
-            model = k.get("issue_cycles_model")
-            if model:
-                cyc = model["simd_cycles_per_wave"] * waves            # SIMD issue-cycles per launch
-                e["valu"]["achieved_Gcyc_per_s"] = cyc / (ms * 1e-3) / 1e9
-                e["valu"]["issue_frac"] = e["valu"]["achieved_Gcyc_per_s"] / SIMD_PEAK_GCYC
-                gui = k["counters"].get("GRBM_GUI_ACTIVE")
-                prof_ms = k.get("ms_under_profiler")
-                if gui and prof_ms:
-                    clock_ghz = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # sum over the 8 XCDs
-                    e["valu"]["clock_GHz_under_profiler"] = clock_ghz
-            acc, req = k["counters"].get("TCP_TOTAL_CACHE_ACCESSES_sum"), k["counters"].get("TCP_TCC_READ_REQ_sum")
-            if acc and req is not None:
-                cyc = acc + TCP_CYCLES_PER_L2_LINE * req                # TCP cycles per launch, all CUs
-                e["l1"] = {"tcp_cache_accesses": acc, "tcp_tcc_read_requests": req,
-                           "accesses_per_CU_cycle_at_2.4GHz": acc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC}
-                if l1_model:       # the gather-bound kernel only: the improvement sweep is VALU-bound
-                    e["l1"].update({"model_cycles": cyc, "cycles_per_l2_served_line": TCP_CYCLES_PER_L2_LINE,
-                                    "model_share_of_launch_time_at_2.4GHz": cyc / (ms * 1e-3) / 1e9 / TCP_PEAK_GCYC,
-                                    "source": "profiles/r02/tcp_gather.txt, l1_path_counters.txt (a model, "
-                                              "not a peak)"})
-            if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
-                e["hbm_traffic_bytes"] = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
-                e["l2_hit_rate"] = k.get("l2_hit_rate")
+        k = ((prof or {}).get("kernels", {}) if counters is None else counters).get(name)
+        if not k or "valu_insts_per_wave" not in k:
+            return e
+        c = k["counters"]
+        waves = c["SQ_WAVES"]
+        units = {}
+        insts = k["valu_insts_per_wave"] * waves
+        ach = insts / sec / 1e9
+        units["valu"] = {"achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s",
+                         "frac": ach / VALU_PEAK_GIPS, "frac_of_measured_peak": ach / VALU_MEASURED_GIPS,
+                         "measured_peak": VALU_MEASURED_GIPS, "insts_per_wave": k["valu_insts_per_wave"],
+                         "waves_per_launch": waves, "class_split_per_wave": k.get("issue_cycles_model")}
+        acc, req = c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), c.get("TCP_TCC_READ_REQ_sum")
+        if acc:
+            ach = acc / sec / 1e9
+            units["l1"] = {"achieved": ach, "peak": TCP_PEAK_GCYC, "unit": "G vector-L1 tag look-ups/s",
+                           "frac": ach / TCP_PEAK_GCYC, "lookups_per_launch": acc, "lookups_per_wave": acc / waves,
+                           "l2_served_lines_per_launch": req, "l1_hit_rate": k.get("l1_hit_rate"),
+                           "pair_loads_floor_lookups_per_64_states": 16 * (1 << (D - 1)),
+                           "with_miss_path": None if req is None else
+                           (acc + TCP_CYCLES_PER_L2_LINE * req) / sec / 1e9 / TCP_PEAK_GCYC,
+                           "note": "with_miss_path adds 1.23 TCP cycles per L2-served line "
+                                   "(profiles/r02/tcp_gather.txt): a model of the unit's busy time, may exceed 1"}
+        if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
+            traffic = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
+            units["hbm"] = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": traffic / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
+                            "l2_hit_rate": k.get("l2_hit_rate")}
+        e["units"] = units
+        gui, prof_ms = c.get("GRBM_GUI_ACTIVE"), k.get("ms_under_profiler")
+        if gui and prof_ms:
+            e["clock_GHz_under_profiler"] = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # summed over the 8 XCDs
         return e
 
     kernels = {
-        "eval_sweep": kernel_entry("pi_eval_sweep_kernel", eval_ms, states_per_launch, bytes_eval, l1_model=True),
+        "eval_sweep": kernel_entry("pi_eval_sweep_kernel", eval_ms, states_per_launch, bytes_eval),
         "improve_sweep": kernel_entry("pi_improve_sweep_kernel", improve_ms, states_per_launch * nA, bytes_improve),
     }
     if converged:
-        # the same two bounds for the policy-iteration state, from ITS committed counters
-        rprof, rpath = load_profile(n, khash, "real") if (args.env == ENV and args.bins == BINS) else (None, None)
-        rk = (rprof or {}).get("kernels", {}).get("pi_eval_sweep_kernel")
-        if rk:
-            c, sec = rk["counters"], converged["ms"] * 1e-3
+        # the same units for the policy-iteration state, from ITS committed counters
+        rprof, rpath = load_profile(args.env, args.bins, n, khash, "real")
+        if rprof:
+            conv = kernel_entry("pi_eval_sweep_kernel", converged["ms"], states_per_launch, bytes_eval,
+                                counters=rprof.get("kernels", {}))
             converged["profile"] = rpath
-            if rk.get("issue_cycles_model"):
-                converged["valu_issue_frac"] = (rk["issue_cycles_model"]["simd_cycles_per_wave"] * c["SQ_WAVES"]
-                                                / sec / 1e9 / SIMD_PEAK_GCYC)
-            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-                converged["l1_gather_model_share_of_launch_time_at_2.4GHz"] = (
-                    (c["TCP_TOTAL_CACHE_ACCESSES_sum"] + TCP_CYCLES_PER_L2_LINE * c.get("TCP_TCC_READ_REQ_sum", 0.0))
-                    / sec / 1e9 / TCP_PEAK_GCYC)
+            converged["units"] = conv.get("units")
         kernels["eval_converged_policy"] = converged
     share = {"eval_sweeps": eval_ms * EVAL_PER_STEP, "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dom = kernels["eval_sweep"] if share["eval_sweeps"] >= share["improve_sweep"] else kernels["improve_sweep"]
-    roofline = {"bound": "valu-issue", "kernel": dom["kernel"], "achieved": None, "peak": SIMD_PEAK_GCYC,
-                "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
-                "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash, "profile": prof_path,
-                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz",
-                "cycles_per_instruction_source": "profiles/r02/valu_issue.txt (tools/valu_issue_bench.hip)"}
-    if "valu" in dom and "issue_frac" in dom["valu"]:
-        v = dom["valu"]
-        roofline["achieved"] = v["achieved_Gcyc_per_s"]
-        roofline["frac"] = v["issue_frac"]
-        roofline["clock_GHz_under_profiler"] = v.get("clock_GHz_under_profiler")
-        roofline["insts_per_wave"] = v["insts_per_wave"]
-        roofline["waves_per_launch"] = v["waves_per_launch"]
-        roofline["issue_cycles_model"] = v["issue_cycles_model"]
-        roofline["valu_Ginst_per_s"] = v["achieved_Ginst_per_s"]
-        roofline["valu_inst_rate_peak_Ginst_per_s"] = VALU_PEAK_GIPS
-        roofline["valu_inst_rate_measured_peak_Ginst_per_s"] = (prof or {}).get("valu_peak_measured_Ginst_per_s")
-    if "l1" in dom:
-        roofline["l1_gather_model"] = dom["l1"]
-    if "hbm_traffic_bytes" in dom:
-        roofline["traffic"] = dom["hbm_traffic_bytes"]
-        roofline["traffic_vs_compulsory"] = dom["hbm_traffic_bytes"] / compulsory
-        roofline["hbm_frac"] = dom["hbm_traffic_bytes"] / (dom["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roofline = {"bound": None, "kernel": dom["kernel"], "achieved": None, "peak": None, "unit": None, "frac": None,
+                "traffic": None, "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash,
+                "profile": prof_path,
+                "peak_source": "MI355X_MICROARCH.md: VALU 1228.8 G wave64 instr/s (2 cycles x 1024 SIMDs x 2.4 GHz); "
+                               "vector L1 one tag look-up per CU and cycle = 614.4 G/s; HBM3E 8 TB/s"}
+    units = dom.get("units")
+    if units:
+        name = max(units, key=lambda u: units[u]["frac"])
+        roofline.update({"bound": {"valu": "valu-issue", "l1": "l1-tag-lookups", "hbm": "hbm"}[name],
+                         "achieved": units[name]["achieved"], "peak": units[name]["peak"],
+                         "unit": units[name]["unit"], "frac": units[name]["frac"], "units": units,
+                         "clock_GHz_under_profiler": dom.get("clock_GHz_under_profiler")})
+        if "hbm" in units:
+            roofline["traffic"] = units["hbm"]["bytes_per_launch"]
+            roofline["traffic_vs_compulsory"] = units["hbm"]["bytes_per_launch"] / compulsory
+            roofline["hbm_frac"] = units["hbm"]["frac"]
     alg_gbps = dom["algorithmic"]["achieved_GBps"]
     roofline_algorithmic = {"bound": "hbm", "kernel": dom["kernel"], "achieved": alg_gbps, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": None, "bytes_per_backup": dom["algorithmic"]["bytes_per_backup"],

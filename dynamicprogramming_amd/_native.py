@@ -57,6 +57,7 @@ SIGNATURES = {
     "pi_plan_segments": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int64, _vp, _vp, ctypes.c_int64]),
     "pi_exchange_plan": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "pi_plan_ranges": (ctypes.c_int64, [_vp, _vp, ctypes.c_int64]),
     "pi_exchange_V": (ctypes.c_int, [_vp, _vp, _vp]),
     "pi_eval_sweeps_sharded": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int,
                                               _vp, _vp]),
@@ -64,11 +65,16 @@ SIGNATURES = {
     "pi_probe_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
     "pi_probe_interp": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
     "pi_probe_coords": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, _vp]),
+    "pi_infer_create": (_vp, [ctypes.c_int, ctypes.c_int, _f32p, _f32p, _i32p, _i32p, _i32p, ctypes.c_int64,
+                              ctypes.c_char_p]),
+    "pi_infer_destroy": (None, [_vp]),
+    "pi_infer_set_policy": (ctypes.c_int, [_vp, _i32p, ctypes.c_int64, _f32p, ctypes.c_int]),
+    "pi_infer_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "pi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 _load_error: Exception | None = None
 
@@ -282,6 +288,16 @@ class Engine:
                 "reach_units": {1: "planes of dimension 0", 2: "rows (i0, i1)"}.get(
                     int(lib().pi_comm_info(self._h, 4)), "none")}
 
+    def plan_ranges(self):
+        """[(kind, begin, end)] of the current exchange plan: kind 0 = swept first, 1 = interior."""
+        fn = lib().pi_plan_ranges
+        m = fn(self._h, None, 0)
+        if m < 0:
+            raise NativeError(f"pi_plan_ranges failed: {last_error()}")
+        buf = (ctypes.c_int64 * (3 * max(int(m), 1)))()
+        fn(self._h, buf, int(m))
+        return [(int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])) for i in range(int(m))]
+
     def exchange_V(self, V_full, stream=0):
         _check(lib().pi_exchange_V(self._h, V_full, stream or None), "pi_exchange_V")
 
@@ -303,6 +319,54 @@ class Engine:
     def close(self) -> None:
         if getattr(self, "_h", None):
             lib().pi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class InferenceEngine:
+    """One pi_infer handle: batched device interpolation of a trained policy (the reference's
+    utils/barycentric.py as one kernel; include/pi_mi355.h "Inference")."""
+
+    def __init__(self, bounds_low, bounds_high, grid_shape, strides, corner_bits, device: int = -1,
+                 cache_dir: Path | str | None = KERNEL_CACHE):
+        L = lib()
+        self._lo = np.ascontiguousarray(bounds_low, dtype=np.float32)
+        self._hi = np.ascontiguousarray(bounds_high, dtype=np.float32)
+        self._shape = np.ascontiguousarray(grid_shape, dtype=np.int32)
+        self._strides = np.ascontiguousarray(strides, dtype=np.int32)
+        self._bits = np.ascontiguousarray(corner_bits, dtype=np.int32)
+        self.D = len(self._shape)
+        assert self._bits.ndim == 2 and self._bits.shape[1] == self.D
+        cdir = None
+        if cache_dir is not None:
+            Path(cache_dir).mkdir(parents=True, exist_ok=True)
+            cdir = str(cache_dir).encode()
+        self._h = L.pi_infer_create(int(device), self.D, self._lo.ctypes.data_as(_f32p), self._hi.ctypes.data_as(_f32p),
+                                    self._shape.ctypes.data_as(_i32p), self._strides.ctypes.data_as(_i32p),
+                                    self._bits.ctypes.data_as(_i32p), len(self._bits), cdir)
+        if not self._h:
+            raise NativeError(f"pi_infer_create failed: {last_error()}")
+        self.device = int(device)
+        self.n_corners = len(self._bits)
+
+    def set_policy(self, policy, action_space) -> None:
+        pol = np.ascontiguousarray(policy, dtype=np.int32)
+        act = np.ascontiguousarray(action_space, dtype=np.float32)
+        _check(lib().pi_infer_set_policy(self._h, pol.ctypes.data_as(_i32p), len(pol), act.ctypes.data_as(_f32p),
+                                         len(act)), "pi_infer_set_policy")
+
+    def query(self, d_points, m, d_actions=0, d_weights=0, d_indices=0, stream=0) -> None:
+        _check(lib().pi_infer_query(self._h, d_points, int(m), d_actions or None, d_weights or None,
+                                    d_indices or None, stream or None), "pi_infer_query")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().pi_infer_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -626,6 +627,24 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
     pi::drop_plan(h);
     h->plan = plan.release();
     return 0;
+}
+
+// The launch ranges of the current plan: up to `cap` triples {kind, begin, end} — kind 0 = swept
+// first (peers wait for rows inside it), kind 1 = interior (swept while the halo travels); a plan
+// without overlap (all-gather, or overlap disabled) reports the whole shard as one kind-0 range.
+int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap) {
+    if (need_plan(h)) return -1;
+    const pi::ShardPlan* p = h->plan;
+    std::vector<std::array<int64_t, 3>> all;
+    if (p->halo && p->comm_stream != nullptr) {
+        for (const auto& r : p->send_ranges) all.push_back({0, r.first, r.second});
+        for (const auto& r : p->interior) all.push_back({1, r.first, r.second});
+    } else if (p->s_end > p->s_begin) {
+        all.push_back({0, p->s_begin, p->s_end});
+    }
+    for (size_t i = 0; ranges && i < all.size() && (int64_t)i < cap; ++i)
+        for (int k = 0; k < 3; ++k) ranges[3 * i + k] = all[i][k];
+    return (int64_t)all.size();
 }
 
 // Make this rank's freshly written shard of `V_full` visible where the other ranks read it.

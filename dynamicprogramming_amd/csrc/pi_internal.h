@@ -97,5 +97,8 @@ int launch_eval(pi_handle* h, const float* V, float* Vnew, const int32_t* policy
                 int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st);
 int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
+// hipRTC (gfx950, -O3 -ffp-contract=off) or the on-disk code-object cache -> image of one translation unit
+int compile_image(const std::string& src, const char* cache_dir, char* log, size_t log_len,
+                  std::vector<char>& image, bool* cache_hit);
 
 }  // namespace pi

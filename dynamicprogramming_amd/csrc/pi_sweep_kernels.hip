@@ -161,7 +161,7 @@ __device__ __forceinline__ void pi_cell_1d(float n, int d, unsigned int& base, f
 // q = a * rcp is within an ulp of the quotient, r = fma(-q, span, a) is the exact residual and
 // fma(r, rcp, q) rounds to the IEEE quotient (Markstein) — proven per divisor on the host for
 // every float32 significand; the run-time condition is only that nothing leaves the normal range:
-// 2^-40 <= |a_d| and sum |a_d| < 2^40 (the host requires 2^-30 <= span <= 2^30).  A NaN or Inf
+// (2^-40 <= |a_d| or a_d == 0) and sum |a_d| < 2^40 (the host requires 2^-30 <= span <= 2^30).  A NaN or Inf
 // coordinate fails the sum test, so the fast path never sees one and may clamp the QUOTIENT to
 // [0, 1] with the fma's free output modifier instead of clamping n with a min and a max:
 // for a finite q both give the same n (RN(q * top) is monotone in q and exact at q = 0 and 1).
@@ -174,14 +174,21 @@ __device__ __forceinline__ void pi_locate(const float (&ns)[PI_D], unsigned int&
     base = 0u;
     bool fast = false;
     if (pi_any_fastdiv()) {
-        float asum = 0.0f, amin = 1.0f;
+        // |a_d| >= 2^-40 OR a_d == 0 in every proven dimension: a successor clamped exactly onto a
+        // lower bound (envs that clip a position or a velocity) has a_d == 0, for which the fast
+        // path is trivially exact (t = r = q = 0).  As one unsigned comparison per dimension:
+        // 2 bits(|a|) - 2 wraps to 0xFFFFFFFE for +-0 and stays below the threshold for every other
+        // value under 2^-40 (denormals included); huge values, Inf and NaN fail the sum test.
+        float asum = 0.0f;
+        unsigned int umin = 0xFFFFFFFFu;
 #pragma unroll
         for (int d = 0; d < PI_D; ++d)
             if (PI_FASTDIV[d]) {
                 asum += fabsf(a[d]);
-                amin = fminf(amin, fabsf(a[d]));
+                const unsigned int u = __float_as_uint(a[d]);
+                umin = min(umin, (u + u) - 2u);
             }
-        fast = (asum < 0x1p40f) & (amin >= 0x1p-40f);
+        fast = (asum < 0x1p40f) & (umin >= 2u * 0x2B800000u - 2u);     // 0x2B800000 = bits(2^-40)
     }
     if (__builtin_expect(fast, 1)) {
 #pragma unroll

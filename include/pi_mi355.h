@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 2
+#define PI_MI355_ABI_VERSION 3
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -210,6 +210,10 @@ int64_t pi_plan_segments(int world, int64_t g0, int64_t stride0, int64_t n_state
  */
 int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, int overlap,
                      int64_t* info, void* stream);
+/* The launch ranges of the current plan: up to cap triples {kind, begin, end}, kind 0 = swept first
+ * (peers wait for rows inside it), 1 = interior (swept while the halo travels).  Returns how many
+ * there are (-1 without a plan).  A plan without overlap reports the shard as one kind-0 range. */
+int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap);
 /* Make this rank's freshly written shard of V_full visible where the other ranks read it. */
 int pi_exchange_V(pi_handle* h, float* V_full, void* stream);
 /*
@@ -231,7 +235,7 @@ int pi_improve_sweep_sharded(pi_handle* h, const float* V, int32_t* policy, cons
  *   pi_probe_interp : pts (m,D) -> idxs (m,2^D) int32, wgts (m,2^D) float
  *                     (get_barycentric_{2,4,6}d, reference corner order)
  *   pi_probe_coords : out[(s - s_begin) * D + d] = coordinate d of grid node s, computed the way
- *                     the sweeps compute it (scalar chunk origin + per-lane carries), with
+ *                     the sweeps compute it (flat index -> per-dimension indices -> LDS bin tables), with
  *                     `chunks_per_workgroup` chunks per workgroup — states_space[s] of :84-87
  */
 int pi_probe_step(pi_handle* h, const float* states, const float* acts, float* next,
@@ -240,6 +244,31 @@ int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, 
                     void* stream);
 int pi_probe_coords(pi_handle* h, int64_t s_begin, int64_t s_end, float* out, int chunks_per_workgroup,
                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inference: the reference's CPU helper utils/barycentric.py as one batched
+ * device kernel — get_barycentric_weights_and_indices (:15-77) and get_optimal_action (:80-112)
+ * for m states per launch, same arithmetic type for type (float64 cell widths, the POINT clamped
+ * to the bounds, weights = float64 products rounded once to float32, corners in the order of the
+ * caller's corner_bits table — itertools.product, MSB first, in the reference :233).  Independent of
+ * pi_handle: needs no env plugin.
+ *   pi_infer_create     host arrays; corner_bits is (n_corners = 2^D, D) int32 of 0/1; device = -1
+ *                       builds the kernel only (compile check without a GPU); cache_dir as pi_compile
+ *   pi_infer_set_policy host arrays: the greedy policy (n_states int32) and the action values; copied
+ *                       to the device once, validated (every entry an index into action_space)
+ *   pi_infer_query      d_points (m, D) float32 on the device; any of the three outputs may be null:
+ *                       d_actions_out (m) float32 = sum_c w[c] * action_space[policy[idx[c]]] (ascending c),
+ *                       d_weights_out (m, 2^D) float32, d_indices_out (m, 2^D) int32.  Asynchronous.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pi_infer pi_infer;
+pi_infer* pi_infer_create(int device, int D, const float* lo, const float* hi, const int32_t* grid_shape,
+                          const int32_t* strides, const int32_t* corner_bits, int64_t n_corners,
+                          const char* cache_dir);
+void pi_infer_destroy(pi_infer* h);
+int pi_infer_set_policy(pi_infer* h, const int32_t* policy, int64_t n_states, const float* action_space,
+                        int n_actions);
+int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actions_out, float* d_weights_out,
+                   int32_t* d_indices_out, void* stream);
 
 /* Tuning: 0 = chunks per workgroup of the evaluation sweeps, 1 = of the improvement / value sweeps
  * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of

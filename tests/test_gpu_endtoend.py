@@ -336,3 +336,60 @@ def test_64_bit_addressing_path_at_2_pow_30_states(cuda_device):
         assert int(d_changed.item()) == o_changed
         del pad_states, o_Vn
     eng.close()
+
+
+def test_device_inference_matches_the_reference_function(cuda_device):
+    """SURVEY row f2, device half: the batched HIP kernel behind utils.barycentric (DevicePolicy /
+    ``device=``) against tests/golden/barycentric_utils.npz — vectors produced in the build container
+    by the reference's OWN utils/barycentric.py (numba typing).  Indices equal and weights bit-equal
+    on 2 000 seeded points per dimension count (out-of-range, exact-node and last-cell points
+    included); the interpolated action within 4 ulp-sized steps of the reference's (its `@` leaves the
+    summation order to BLAS; the kernel sums in ascending corner order); and the device path equals
+    this package's numpy twin exactly on a larger batch."""
+    from itertools import product
+    from utils.barycentric import DevicePolicy, get_barycentric_weights_and_indices, get_optimal_action
+    gold = np.load(H.GOLDEN / "barycentric_utils.npz")
+    for D in (2, 4, 6):
+        name, shape = str(gold[f"d{D}_env"]), tuple(int(x) for x in gold[f"d{D}_shape"])
+        bins = H.env_bins(name, shape)
+        lo, hi, gshape, strides = oracle.grid_metadata(bins)
+        bits = np.array(list(product([0, 1], repeat=D)), dtype=np.int32)
+        pts = gold[f"d{D}_points"]
+        policy, actions = gold[f"d{D}_policy"], gold[f"d{D}_actions"]
+        dp = DevicePolicy(policy, actions, lo, hi, gshape, strides, bits, device=cuda_device)
+        w, idx = dp.weights_and_indices(pts)
+        assert w.dtype == np.float32 and idx.dtype == np.int32 and w.shape == (len(pts), 1 << D)
+        assert np.array_equal(idx, gold[f"d{D}_indices"])
+        H.assert_bits_equal(w, gold[f"d{D}_weights_numba"], f"D={D} device weights")
+        act = dp(pts[:300])
+        want = gold[f"d{D}_optimal_action"]
+        tol = 4 * np.spacing(np.float32(np.abs(actions).max())) * (1 << D) / 4
+        assert act.dtype == np.float32 and np.max(np.abs(act.astype(np.float64) - want)) <= tol
+        # the module-level functions with device=: a batch, and a single state like the reference's call
+        w2, idx2 = get_barycentric_weights_and_indices(pts[:64], lo, hi, gshape, strides, bits, device=cuda_device)
+        assert np.array_equal(idx2, idx[:64]) and np.array_equal(w2.view(np.uint32), w[:64].view(np.uint32))
+        one = get_optimal_action(pts[7], policy, actions, lo, hi, gshape, strides, bits, device=cuda_device)
+        assert np.ndim(one) == 0 and np.float32(one) == act[7]
+        # against the numpy twin on a bigger batch, incl. points far outside the grid
+        rng = np.random.default_rng(D)
+        big = H.sample_states(rng, bins, 50_000)
+        big[::97] *= 40.0
+        wn, idxn = get_barycentric_weights_and_indices(big, lo, hi, gshape, strides, bits)
+        wd, idxd = dp.weights_and_indices(big)
+        assert np.array_equal(idxd, idxn)
+        H.assert_bits_equal(wd, wn, f"D={D} device vs numpy weights")
+        seq = np.zeros(len(big), np.float32)
+        for c in range(1 << D):                                    # ascending corners, multiply then add
+            seq = seq + wn[:, c] * actions[policy[idxn[:, c]]]
+        H.assert_bits_equal(dp(big), seq, f"D={D} device action")
+        # a permuted corner table is honoured (the reference takes corner_bits as an argument)
+        perm = rng.permutation(1 << D)
+        dq = DevicePolicy(policy, actions, lo, hi, gshape, strides, bits[perm], device=cuda_device)
+        wq, idxq = dq.weights_and_indices(pts[:128])
+        assert np.array_equal(idxq, idx[:128][:, perm]) and np.array_equal(wq.view(np.uint32), w[:128][:, perm].view(np.uint32))
+        dq.close()
+        dp.close()
+    with pytest.raises(_native.NativeError, match="not an index"):
+        bits = np.array(list(product([0, 1], repeat=2)), dtype=np.int32)
+        DevicePolicy(np.full(6, 9, np.int32), np.zeros(3, np.float32), [0, 0], [1, 1], [2, 3], [3, 1], bits,
+                     device=cuda_device)

@@ -677,8 +677,10 @@ def test_small_batches_replay_as_graphs(cuda_device):
 
 def test_interpolation_division_guard_edges(cuda_device):
     """The reciprocal-multiply division of the interpolation is only taken for 2^-40 <= |s - lo|
-    and sum |s - lo| < 2^40; zero, denormal, huge, infinite and NaN coordinates must take the IEEE
-    path and land where the reference's arithmetic puts them (indices exact, weights bit-exact)."""
+    (or s - lo == 0 exactly: a successor clamped onto a lower bound, trivially exact on that path)
+    and sum |s - lo| < 2^40; denormal, tiny, huge, infinite and NaN coordinates must take the IEEE
+    path; every point lands where the reference's arithmetic puts it (indices exact, weights
+    bit-exact) whichever path its lane takes."""
     torch = _torch()
     name, shape = "cartpole", (9, 7, 11, 5)
     eng, bins, acts = _engine(name, shape, cuda_device)
@@ -694,6 +696,11 @@ def test_interpolation_division_guard_edges(cuda_device):
         pts[16 * k + 4, :] = v
         pts[16 * k + 5, :] = lo            # s - lo == 0 exactly
         pts[16 * k + 6, :] = hi
+        # on a lower bound in some dimensions (fast path admits a == 0) and `v` away from it in the others
+        pts[16 * k + 7, :] = lo
+        pts[16 * k + 7, 1::2] = (lo[1::2] + v) if np.isfinite(v) and abs(v) < 1e20 else v
+        pts[16 * k + 8, :] = lo
+        pts[16 * k + 8, 0] = 0.5 * (lo[0] + hi[0])   # one ordinary coordinate, three exactly on lo
     chk = H.oracle_for(name)
     o_idx, o_w = chk.interp(pts, lo, hi, gshape, strides)
     d_pts = _dev(pts, cuda_device)

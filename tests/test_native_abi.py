@@ -233,3 +233,34 @@ def test_reciprocal_division_refuses_out_of_range_divisors():
                          np.array([0.0], np.float32), device=-1)
     assert [eng.info(20), eng.info(21)] == [0, 1]
     eng.close()
+
+
+def test_inference_kernel_builds_without_a_gpu_and_validates_arguments(tmp_path):
+    """pi_infer_* (the device twin of utils/barycentric.py): the kernel compiles for gfx950 for every D
+    through hipRTC with a host-only handle; bad arguments fail loudly; without a GPU the Python
+    front end raises instead of computing somewhere else."""
+    from itertools import product
+    for D in (2, 4, 6):
+        bits = np.array(list(product([0, 1], repeat=D)), dtype=np.int32)
+        shape = [5, 4, 6, 3, 4, 5][:D]
+        strides = np.cumprod([1] + shape[::-1][:-1])[::-1]
+        eng = _native.InferenceEngine([0.0] * D, [1.0] * D, shape, strides, bits, device=-1, cache_dir=tmp_path)
+        assert eng.n_corners == 1 << D
+        with pytest.raises(_native.NativeError, match="host-only"):
+            eng.query(1, 4, 2)
+        with pytest.raises(_native.NativeError, match="host-only"):
+            eng.set_policy(np.zeros(int(np.prod(shape)), np.int32), [0.0])
+        eng.close()
+    assert len(list(tmp_path.glob("pi_*.hsaco"))) == 3
+    bits = np.array(list(product([0, 1], repeat=2)), dtype=np.int32)
+    with pytest.raises(_native.NativeError, match="2\\^D rows"):
+        _native.InferenceEngine([0, 0], [1, 1], [3, 3], [3, 1], bits[:3], device=-1, cache_dir=None)
+    with pytest.raises(_native.NativeError, match="0 or 1"):
+        _native.InferenceEngine([0, 0], [1, 1], [3, 3], [3, 1], bits * 2, device=-1, cache_dir=None)
+    with pytest.raises(_native.NativeError, match="exceed bounds_low"):
+        _native.InferenceEngine([0, 1], [1, 1], [3, 3], [3, 1], bits, device=-1, cache_dir=None)
+    import torch
+    if not torch.cuda.is_available():
+        from utils.barycentric import DevicePolicy
+        with pytest.raises(RuntimeError, match="ROCm GPU"):
+            DevicePolicy(None, None, [0, 0], [1, 1], [3, 3], [3, 1], bits)
