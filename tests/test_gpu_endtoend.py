@@ -448,3 +448,56 @@ def test_full_size_c5_swingup_windows(cuda_device):
         assert int(d_changed.item()) == o_changed
         del pad_states, o_Vn
     eng.close()
+
+
+def test_plan_ranges_tile_the_shard_and_a_missing_peer_is_an_error_not_a_hang(cuda_device, monkeypatch):
+    """The sharded driver's launch ranges (pi_plan_ranges) of every logical rank are disjoint, cover
+    exactly its shard and put every row a peer waits for into a swept-first range; and the in-process
+    transport bounds its host waits: a rank whose peer never arrives gets an error after
+    PI_MI355_COMM_TIMEOUT seconds (failure -> abort with a message, never a hang),
+    after which the handle refuses sharded sweeps until a new plan is made."""
+    import threading
+    import time
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_EXCHANGE", "halo")
+    name, shape, world = "cartpole_swingup", (18, 7, 9, 8), 4
+    cls = envs.ENVS[name]
+    cfg = envs.CudaPIConfig(**cls.CONFIG)
+    group = f"ranges-{uuid.uuid4().hex}"
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+                s = cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device,
+                        transport=T.NativeTransport.local(r, world, group))
+                out[r] = (s._s_begin, s._s_end, s._backend.engine.plan_ranges(), dict(s._comm.info))
+                s._backend.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and all(o is not None for o in out), errors
+    for a, b, ranges, info in out:
+        assert info["mode"] == "halo" and ranges
+        assert {k for k, _, _ in ranges} <= {0, 1}
+        spans = sorted((lo, hi) for _, lo, hi in ranges)
+        assert spans[0][0] == a and spans[-1][1] == b
+        assert all(x[1] == y[0] for x, y in zip(spans, spans[1:]))           # disjoint, no holes
+        assert sum(1 for k, _, _ in ranges if k == 0) == info["send_ranges"]
+        assert sum(1 for k, _, _ in ranges if k == 1) == info["interior_ranges"]
+
+    # a peer that never shows up: bounded wait, then an error
+    monkeypatch.setenv("PI_MI355_COMM_TIMEOUT", "2")
+    lonely = f"lonely-{uuid.uuid4().hex}"
+    t0 = time.perf_counter()
+    with pytest.raises(_native.NativeError, match="gave up waiting"):
+        cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device,
+            transport=T.NativeTransport.local(0, 2, lonely))             # the plan's all-gather needs rank 1
+    assert 1.5 < time.perf_counter() - t0 < 60.0
