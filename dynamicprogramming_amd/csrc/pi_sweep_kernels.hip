@@ -23,13 +23,17 @@
 // sweep, an LDS-resident kernel that runs whole batches of sweeps (or a whole policy evaluation)
 // of a small grid in one launch, and the reach probes the multi-GPU exchange is planned from.
 //
-// What bounds these kernels on MI355X, and what the code does about it (DESIGN.md section 4,
-// profiles/r02): the improvement sweep is bound by fp32 VALU *issue*, the evaluation sweep runs at
-// ~85 % of that bound and spends the rest in the L1-miss path of its divergent corner gather;
-// wave64 instructions do not all cost the same — v_fma/v_mul/v_add/v_and/v_xor/v_add_u32 issue in ~2.3 cycles per SIMD,
-// everything else (compares, selects, min/max, conversions, shifts, integer multiplies, the
-// v_div_* helpers, packed and fp64 ops) in ~4.2, transcendentals in ~8.2
-// (tools/valu_issue_bench.hip).  So:
+// What bounds these kernels on MI355X, and what the code does about it (DESIGN.md sections 4 and 5,
+// profiles/r03): in 4-D and 6-D the evaluation sweep is bound by the vector L1 (TCP) of its divergent corner
+// gather — a wave-wide 8-byte load costs max(16, distinct 128-byte lines) tag look-ups and every line that
+// misses waits ~200-250 cycles for L2 — with the VALU at 0.49 (80^4) / 0.23 (25^6) of its 1 228.8 G
+// instructions/s and HBM at 0.27 / 0.18 of 8 TB/s; the improvement sweep is co-limited by VALU issue (0.54)
+// and the same unit.  VALU issue is ~2.2 cycles per wave64 instruction per SIMD for ANY mix that is at
+// least half fp32 fma/mul/add: compares, selects, min/max, conversions, shifts, integer multiplies and
+// the v_div_* helpers cost 4.15 cycles (transcendentals 8.15) only in a stream of nothing else — mixed in,
+// clustered or not, they are hidden (tools/valu_issue_bench.hip, profiles/r03/valu_issue.txt).  So the
+// code keeps the instruction count low, keeps every load in flight early, and touches as few lines per
+// wave as the dynamics allow:
 //   * the interpolation's IEEE divisions (s - lo) / (hi - lo) have a per-dimension constant
 //     divisor: they run as a * rcp, one residual fma and one correction fma — bit-identical to
 //     the IEEE quotient for every dividend in [2^-40, 2^40], which the host PROVES per divisor
