@@ -10,8 +10,9 @@ reference is imported or executed), pulls out
   * the ``_dynamics_cuda_src`` string of each runner's env class,
 
 writes both to a temporary directory and compiles oracle/ref_driver.cpp around them into
-``~/.cache/pi_mi355_ref/libref_<env>_<hash of the extracted text>.so`` (a per-user directory with
-mode 0700; ``PI_MI355_REF_DIR`` overrides) — OUTSIDE the repository tree, so that neither reference
+``$TMPDIR/pi_mi355_ref-<uid>/libref_<env>_<hash of the extracted text>.so`` (a per-user directory,
+created with mode 0700 and refused unless it belongs to this user with that mode; ``PI_MI355_REF_DIR``
+overrides) — OUTSIDE the repository tree, so that neither reference
 text nor anything compiled from it can travel to the GPU box with a snapshot of the repo
 (tests/test_hygiene.py checks the tree).
 ``load(env)`` returns an ``oracle.OracleLib`` over that shared object, which
@@ -31,7 +32,8 @@ from . import OracleLib, CXX
 
 REFERENCE = Path("/root/reference")
 _HERE = Path(__file__).resolve().parent
-REF_DIR = Path(os.environ.get("PI_MI355_REF_DIR", str(Path.home() / ".cache" / "pi_mi355_ref")))
+REF_DIR = Path(os.environ.get("PI_MI355_REF_DIR",
+                              str(Path(tempfile.gettempdir()) / f"pi_mi355_ref-{os.getuid()}")))
 
 # env name -> (runner file, class name, D)
 RUNNERS = {
