@@ -104,6 +104,16 @@ def test_committed_bench_evidence_matches_the_kernels_and_the_contract():
         assert units["valu"]["peak"] == 1228.8 and units["hbm"]["peak"] == 8000.0 and abs(units["l1"]["peak"] - 614.4) < 1e-9
         for u in units.values():
             assert 0.0 < u["frac"] <= 1.0, (path.name, u)
+        # ... and every fraction can be recomputed from the committed profile and the line's own launch time
+        k = prof["kernels"][r["kernel"]]
+        sec = r["avg_launch_ms"] * 1e-3
+        valu = k["valu_insts_per_wave"] * k["counters"]["SQ_WAVES"] / sec / 1e9
+        l1 = k["counters"]["TCP_TOTAL_CACHE_ACCESSES_sum"] / sec / 1e9
+        hbm = (2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]) / sec / 1e9
+        for name, got in (("valu", valu), ("l1", l1), ("hbm", hbm)):
+            assert abs(units[name]["achieved"] - got) <= 1e-9 * got, (path.name, name)
+            assert abs(units[name]["frac"] - got / units[name]["peak"]) <= 1e-12, (path.name, name)
+        assert abs(r["traffic"] - (2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"])) < 1.0
         assert 0.0 < r["hbm_frac"] <= 1.0 and r["traffic"] > 0
     if stale:
         pytest.skip(f"kernels changed since {latest.name} was made ({', '.join(stale)}): "
