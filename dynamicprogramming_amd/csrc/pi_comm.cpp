@@ -519,7 +519,7 @@ int64_t pi_plan_segments(int world, int64_t g0, int64_t stride0, int64_t n_state
 int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, int overlap,
                      int64_t* info, void* stream) {
     if (need_comm(h)) return 1;
-    if (!term || per < 1) return fail("bad argument");
+    if (per < 1) return fail("bad argument");
     pi::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     pi::Comm* c = h->comm;
@@ -664,7 +664,7 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
                            void* stream) {
     if (need_plan(h)) return 1;
     if (n_sweeps < 0) return fail("n_sweeps < 0");
-    if (!Va || !Vb || !policy || !term) return fail("null device pointer");
+    if (!Va || !Vb || !policy) return fail("null device pointer");
     if (Va == Vb) return fail("Va and Vb must be different buffers (Jacobi sweep)");
     if (n_sweeps == 0) return 0;
     pi::DeviceGuard guard(h->device);

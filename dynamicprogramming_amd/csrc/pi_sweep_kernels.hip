@@ -389,16 +389,22 @@ __device__ __forceinline__ const T* pi_lane_ptr(const T* chunk_base, unsigned in
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(chunk_base) +
                                       lane * (unsigned int)sizeof(T));
 }
+// term == nullptr: the grid has no terminal states (the caller's promise; the solver passes it for envs
+// whose mask is empty) — no mask stream at all.  need_old == false: nobody will look at the state's old
+// value (no terminal state to copy, no residual asked of this launch), so it is not read either: on a
+// grid without terminal states 24 of 25 evaluation sweeps stream 4 B per state (the action) instead of 9.
 __device__ __forceinline__ PiStateIn pi_load_state(const float* __restrict__ V,
                                                    const int* __restrict__ policy,
                                                    const unsigned char* __restrict__ term,
-                                                   long long sb, unsigned int lane) {
+                                                   long long sb, unsigned int lane, bool need_old) {
     PiStateIn in;
     // policy and mask are read exactly once per sweep: stream them (nt) so they do not displace
     // V lines, which neighbouring states re-read, from L2 / Infinity Cache.
-    in.term = __builtin_nontemporal_load(pi_lane_ptr(term + sb, lane));
+    in.term = 0;
+    if (term != nullptr) in.term = __builtin_nontemporal_load(pi_lane_ptr(term + sb, lane));
     in.action = __builtin_nontemporal_load(pi_lane_ptr(policy + sb, lane));
-    in.v_old = *pi_lane_ptr(V + sb, lane);
+    in.v_old = 0.0f;
+    if (need_old) in.v_old = *pi_lane_ptr(V + sb, lane);
     return in;
 }
 template <typename T>
@@ -423,7 +429,8 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
     long long sb = s_begin + chunk0 * PI_BLOCK_EVAL;                     // first state of the chunk
     // lanes past s_end (tail of the last chunk) shadow the last valid state and store nothing
     unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
-    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
+    const bool need_old = delta_bits != nullptr || term != nullptr;      // launch-uniform
+    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane, need_old);
     pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
     __syncthreads();
 
@@ -435,7 +442,7 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
         if (k + 1 < n_here) {                                        // prefetch the next chunk's inputs
             sb += PI_BLOCK_EVAL;
             lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
-            nxt = pi_load_state(V, policy, term, sb, lane);
+            nxt = pi_load_state(V, policy, term, sb, lane, need_old);
         }
         float nv = cur.v_old;
         if (!cur.term) {
@@ -535,7 +542,7 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
         if (s < N) {
             v_cur[j] = lv[s];
             kind[j] = 1u;
-            if (!term[s]) {
+            if (term == nullptr || !term[s]) {
                 float x[PI_D], ns[PI_D];
                 pi_state_coords(s, lds_tab, x);
                 bool done;
@@ -648,7 +655,9 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
     const unsigned int tid = threadIdx.x;
     long long sb = s_begin + chunk0 * PI_BLOCK_IMPROVE;
     unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_IMPROVE) - 1));
-    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane);
+    // the old value is only needed by the value sweep (residual, terminal copy)
+    const bool need_old = WRITE_V && (delta_bits != nullptr || term != nullptr);
+    PiStateIn nxt = pi_load_state(V, policy, term, sb, lane, need_old);
     pi_stage_table<PI_BLOCK_IMPROVE>(tab, lds_tab);
     __syncthreads();
 
@@ -661,7 +670,7 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
         if (k + 1 < n_here) {
             sb += PI_BLOCK_IMPROVE;
             lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_IMPROVE) - 1));
-            nxt = pi_load_state(V, policy, term, sb, lane);
+            nxt = pi_load_state(V, policy, term, sb, lane, need_old);
         }
         const bool live = tid == lane_c;
         if (!cur.term) {
@@ -760,7 +769,7 @@ pi_reach_planes_kernel(const unsigned char* __restrict__ term, const float* __re
         if (d == dim) { stride_dim = (unsigned int)PI_GRID.stride[d]; g_dim = (unsigned int)PI_GRID.g[d]; }
     for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
         const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
-        if (s >= s_end || term[s]) continue;
+        if (s >= s_end || (term != nullptr && term[s])) continue;
         float x[PI_D];
         pi_state_coords((unsigned int)s, lds_tab, x);
         int last = -1;
@@ -815,7 +824,7 @@ pi_reach_units_kernel(const unsigned char* __restrict__ term, const float* __res
     constexpr unsigned int st0 = PI_GRID.stride[0], st1 = PI_D >= 2 ? PI_GRID.stride[1] : 1;
     for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
         const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
-        if (s >= s_end || term[s]) continue;
+        if (s >= s_end || (term != nullptr && term[s])) continue;
         float x[PI_D];
         pi_state_coords((unsigned int)s, lds_tab, x);
         int last = -1;

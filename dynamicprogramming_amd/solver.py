@@ -87,8 +87,14 @@ class HipSweepBackend:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
+    @staticmethod
+    def _ptr(term) -> int:
+        """Device pointer of the terminal mask, or NULL: `None` = "this grid has no terminal states"
+        (the kernels then read no mask and, on sweeps without a residual, no old value either)."""
+        return 0 if term is None else term.data_ptr()
+
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
-        self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), term.data_ptr(),
+        self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), self._ptr(term),
                                 s_begin, s_end, gamma, n_sweeps,
                                 0 if d_delta is None else d_delta.data_ptr(), self._stream())
 
@@ -105,7 +111,7 @@ class HipSweepBackend:
         looks = max_sweeps // check_interval + 2
         out = torch.zeros(looks + 1, dtype=torch.float32, device=self.device)     # [log..., sweeps as int32 bits]
         sweeps = out[looks:].view(torch.int32)
-        self.engine.policy_evaluation(V.data_ptr(), policy.data_ptr(), term.data_ptr(), gamma, theta,
+        self.engine.policy_evaluation(V.data_ptr(), policy.data_ptr(), self._ptr(term), gamma, theta,
                                       max_sweeps, check_interval, sweeps.data_ptr(), 0, out.data_ptr(),
                                       self._stream())
         host = out.cpu()
@@ -117,7 +123,7 @@ class HipSweepBackend:
         """bool[n_planes]: planes of V along `dim` the states of the range can read (any action)."""
         words = (n_planes + 31) // 32
         bitmap = self.torch.zeros(words, dtype=self.torch.int32, device=self.device)
-        self.engine.reach_planes(term.data_ptr(), s_begin, s_end, bitmap.data_ptr(), self._stream(), dim=dim)
+        self.engine.reach_planes(self._ptr(term), s_begin, s_end, bitmap.data_ptr(), self._stream(), dim=dim)
         bits = bitmap.cpu().numpy().view(np.uint32)
         return ((bits[np.arange(n_planes) >> 5] >> (np.arange(n_planes) & 31).astype(np.uint32)) & 1).astype(bool)
 
@@ -126,17 +132,17 @@ class HipSweepBackend:
         (i0, i1)) the states of the range can read under any action (pi_reach_units)."""
         n_units = int(np.prod(self.engine._shape[:depth]))
         bitmap = self.torch.zeros((n_units + 31) // 32, dtype=self.torch.int32, device=self.device)
-        self.engine.reach_units(term.data_ptr(), s_begin, s_end, depth, bitmap.data_ptr(), self._stream())
+        self.engine.reach_units(self._ptr(term), s_begin, s_end, depth, bitmap.data_ptr(), self._stream())
         bits = bitmap.cpu().numpy().view(np.uint32)
         return ((bits[np.arange(n_units) >> 5] >> (np.arange(n_units) & 31).astype(np.uint32)) & 1).astype(bool)
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
-        self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), term.data_ptr(), s_begin, s_end,
+        self.engine.improve_sweep(V.data_ptr(), policy.data_ptr(), self._ptr(term), s_begin, s_end,
                                   gamma, 0 if d_changed is None else d_changed.data_ptr(),
                                   self._stream())
 
     def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta, d_changed):
-        self.engine.value_sweep(V.data_ptr(), Vnew.data_ptr(), policy.data_ptr(), term.data_ptr(),
+        self.engine.value_sweep(V.data_ptr(), Vnew.data_ptr(), policy.data_ptr(), self._ptr(term),
                                 s_begin, s_end, gamma, 0 if d_delta is None else d_delta.data_ptr(),
                                 0 if d_changed is None else d_changed.data_ptr(), self._stream())
 
@@ -276,6 +282,9 @@ class _CudaPolicyIterationBase(abc.ABC):
             self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
             logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
         self.d_new_value_function.copy_(self.d_value_function)
+        # What the sweeps are given as the mask: the tensor, or None when no grid node is terminal — the
+        # kernels then stream neither the mask nor (on sweeps without a residual) the old values.
+        self._term_arg = self.d_terminal_mask if (terminal_mask is not None and terminal_mask.any()) else None
         if self._comm is not None:
             self._comm.plan(self)
             if self._comm.halo_elems >= 0:
@@ -283,6 +292,14 @@ class _CudaPolicyIterationBase(abc.ABC):
                             f"{self._comm.halo_elems * 4 / 2**20:.1f} MiB per sweep instead of "
                             f"{(self._n_pad - self._shard_len) * 4 / 2**20:.1f} MiB")
         logger.success("Kernels compiled. Device memory allocated.")
+
+    def _mask_arg(self):
+        """The terminal mask as the sweeps get it: the device tensor, or None when no grid node is
+        terminal.  A subclass that replaces _allocate_tensors_and_compile wholesale and never sets
+        `_term_arg` gets the tensor it allocated."""
+        if hasattr(self, "_term_arg"):
+            return self._term_arg
+        return self.d_terminal_mask
 
     def _seed_values(self, mask: np.ndarray, value: float) -> None:
         """Set V (both Jacobi buffers) on the masked grid nodes — supported way to give goal
@@ -324,7 +341,7 @@ class _CudaPolicyIterationBase(abc.ABC):
             self._comm.evaluation_sweeps(self, n, gamma)
             return
         self._backend.eval_sweeps(self.d_value_function, self.d_new_value_function, self.d_policy,
-                                  self.d_terminal_mask, self._s_begin, self._s_end, gamma, n,
+                                  self._mask_arg(), self._s_begin, self._s_end, gamma, n,
                                   self._d_delta)
         if n & 1:
             self.d_value_function, self.d_new_value_function = (
@@ -336,7 +353,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         if self._comm is not None:
             self._comm.improvement_sweep(self, gamma)
             return
-        self._backend.improve_sweep(self.d_value_function, self.d_policy, self.d_terminal_mask,
+        self._backend.improve_sweep(self.d_value_function, self.d_policy, self._mask_arg(),
                                     self._s_begin, self._s_end, gamma, self._d_changed)
 
     def policy_evaluation(self) -> float:
@@ -375,7 +392,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         residuals, same V); the log lines are written afterwards from the residuals it recorded."""
         cfg = self.config
         sweeps, looked = self._backend.policy_evaluation(self.d_value_function, self.d_policy,
-                                                         self.d_terminal_mask, gamma, float(cfg.theta),
+                                                         self._mask_arg(), gamma, float(cfg.theta),
                                                          int(cfg.max_eval_iter), SYNC_INTERVAL)
         delta = float(looked[-1])
         for k, r in enumerate(looked):
@@ -433,7 +450,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         for i in range(limit):
             check = i % SYNC_INTERVAL == 0 or i == limit - 1
             self._backend.value_sweep(self.d_value_function, self.d_new_value_function, self.d_policy,
-                                      self.d_terminal_mask, self._s_begin, self._s_end, gamma,
+                                      self._mask_arg(), self._s_begin, self._s_end, gamma,
                                       self._d_delta if check else None, None)
             if self._comm is not None:
                 self._comm.exchange(self, self.d_new_value_function)
@@ -498,7 +515,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         n = self.n_states
         self.value_function = self.d_value_function[:n].cpu().numpy()
         self.policy = self.d_policy[:n].cpu().numpy()
-        for attr in ["d_terminal_mask", "d_value_function", "d_new_value_function", "d_policy",
+        for attr in ["d_terminal_mask", "_term_arg", "d_value_function", "d_new_value_function", "d_policy",
                      "_d_delta", "_d_changed"]:
             if hasattr(self, attr):
                 delattr(self, attr)

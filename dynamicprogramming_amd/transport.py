@@ -69,7 +69,7 @@ class NativeTransport:
     def plan(self, solver) -> None:
         mode = {"auto": 0, "allgather": 1, "halo": 2}[os.environ.get("PI_MI355_EXCHANGE", "auto")]
         overlap = os.environ.get("PI_MI355_OVERLAP", "1") != "0"
-        self.info = self.engine.exchange_plan(solver.d_terminal_mask.data_ptr(), solver._shard_len,
+        self.info = self.engine.exchange_plan(solver._backend._ptr(solver._mask_arg()), solver._shard_len,
                                               mode, overlap, self._stream())
         self.halo_elems = self.info["recv_elems"] if self.info["mode"] == "halo" else -1
 
@@ -77,7 +77,7 @@ class NativeTransport:
     def evaluation_sweeps(self, solver, n: int, gamma: float) -> None:
         self.engine.eval_sweeps_sharded(solver.d_value_function.data_ptr(),
                                         solver.d_new_value_function.data_ptr(),
-                                        solver.d_policy.data_ptr(), solver.d_terminal_mask.data_ptr(),
+                                        solver.d_policy.data_ptr(), solver._backend._ptr(solver._mask_arg()),
                                         gamma, n, solver._d_delta.data_ptr(), self._stream())
         if n & 1:
             solver.d_value_function, solver.d_new_value_function = (
@@ -85,7 +85,7 @@ class NativeTransport:
 
     def improvement_sweep(self, solver, gamma: float) -> None:
         self.engine.improve_sweep_sharded(solver.d_value_function.data_ptr(), solver.d_policy.data_ptr(),
-                                          solver.d_terminal_mask.data_ptr(), gamma,
+                                          solver._backend._ptr(solver._mask_arg()), gamma,
                                           solver._d_changed.data_ptr(), self._stream())
 
     def exchange(self, solver, full) -> None:

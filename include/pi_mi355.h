@@ -81,6 +81,9 @@ size_t pi_kernel_source(pi_handle* h, const char* dynamics_src, char* buf, size_
  * max_abs_diff reduction launched after it (:318-320): when d_delta != NULL it is
  * zeroed on `stream` and receives max|Vnew - V| over the range (float, device).
  * V is read over the whole grid; Vnew/policy/term only over the range.
+ * term == NULL means "this grid has no terminal states" (the caller's promise; every sweep, reach and
+ * sharded entry point accepts it): the kernels then stream no mask, and a sweep that is not asked for a
+ * residual does not read the states' old values either — 4 B per state instead of 9 besides the gather.
  */
 int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* policy,
                   const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,

@@ -53,7 +53,7 @@ class TorchDistTransport:
         stride0 = n // g0
         mine = np.zeros(g0, dtype=bool)
         if solver._s_end > solver._s_begin:
-            mine = solver._backend.reach_units(solver.d_terminal_mask, solver._s_begin, solver._s_end, depth)
+            mine = solver._backend.reach_units(solver._mask_arg(), solver._s_begin, solver._s_end, depth)
         allbits = torch.zeros(self.world * g0, dtype=torch.uint8)
         dist.all_gather_into_tensor(allbits, torch.from_numpy(mine.astype(np.uint8)), group=self.group)
         reach = allbits.numpy().astype(bool).reshape(self.world, g0)
@@ -117,12 +117,12 @@ class TorchDistTransport:
                 parts = torch.zeros(len(self._send_ranges) + len(self._interior) + 1)
                 i = 0
                 for a, b in self._send_ranges:
-                    be.eval_sweeps(src, dst, solver.d_policy, solver.d_terminal_mask, a, b, gamma, 1,
+                    be.eval_sweeps(src, dst, solver.d_policy, solver._mask_arg(), a, b, gamma, 1,
                                    parts[i:i + 1] if last else None)
                     i += 1
                 reqs = self._post(dst)
                 for a, b in self._interior:
-                    be.eval_sweeps(src, dst, solver.d_policy, solver.d_terminal_mask, a, b, gamma, 1,
+                    be.eval_sweeps(src, dst, solver.d_policy, solver._mask_arg(), a, b, gamma, 1,
                                    parts[i:i + 1] if last else None)
                     i += 1
                 for req in reqs:
@@ -132,7 +132,7 @@ class TorchDistTransport:
                 if last:
                     solver._d_delta[0] = parts[:i].max() if i else 0.0
             else:
-                be.eval_sweeps(src, dst, solver.d_policy, solver.d_terminal_mask, solver._s_begin,
+                be.eval_sweeps(src, dst, solver.d_policy, solver._mask_arg(), solver._s_begin,
                                solver._s_end, gamma, 1, solver._d_delta if last else None)
                 self._all_gather_shards(solver, dst)
             solver.d_value_function, solver.d_new_value_function = dst, src
@@ -140,7 +140,7 @@ class TorchDistTransport:
 
     def improvement_sweep(self, solver, gamma: float) -> None:
         import torch.distributed as dist
-        solver._backend.improve_sweep(solver.d_value_function, solver.d_policy, solver.d_terminal_mask,
+        solver._backend.improve_sweep(solver.d_value_function, solver.d_policy, solver._mask_arg(),
                                       solver._s_begin, solver._s_end, gamma, solver._d_changed)
         dist.all_reduce(solver._d_changed, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -110,6 +110,10 @@ class OracleSweepBackend:
         self.n = len(self.states)
         self.calls = {"eval": 0, "improve": 0}
 
+    def _mask(self, term):
+        """The solver passes None for a grid without terminal states (the product then streams no mask)."""
+        return np.zeros(self.n, dtype=np.uint8) if term is None else term.numpy()[: self.n]
+
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta,
                     rebuild=True):
         n = self.n
@@ -117,7 +121,7 @@ class OracleSweepBackend:
             src, dst = (Vb, Va) if (i & 1) else (Va, Vb)
             out = dst.numpy()
             _, delta = self.lib.eval_sweep(self.states, self.actions, policy.numpy()[:n],
-                                           src.numpy()[:n], term.numpy()[:n], self.lo, self.hi,
+                                           src.numpy()[:n], self._mask(term), self.lo, self.hi,
                                            self.shape, self.strides, gamma, s_begin, s_end,
                                            out=out[:n])
             self.calls["eval"] += 1
@@ -128,7 +132,7 @@ class OracleSweepBackend:
         """CPU restatement of pi_reach_planes: planes of every successor cell (+1), any action."""
         n = self.n
         out = np.zeros(n_planes, dtype=bool)
-        live = ~term.numpy()[:n][s_begin:s_end].astype(bool)
+        live = ~self._mask(term)[s_begin:s_end].astype(bool)
         st = self.states[s_begin:s_end][live]
         for a in self.actions:
             nxt, _, done = self.lib.step(st, a)
@@ -143,7 +147,7 @@ class OracleSweepBackend:
         n = self.n
         unit = int(self.strides[depth - 1])
         out = np.zeros(n // unit, dtype=bool)
-        live = ~term.numpy()[:n][s_begin:s_end].astype(bool)
+        live = ~self._mask(term)[s_begin:s_end].astype(bool)
         st = self.states[s_begin:s_end][live]
         for a in self.actions:
             nxt, _, done = self.lib.step(st, a)
@@ -154,7 +158,7 @@ class OracleSweepBackend:
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         n = self.n
         new_pol, changed = self.lib.improve_sweep(self.states, self.actions, policy.numpy()[:n],
-                                                  V.numpy()[:n], term.numpy()[:n], self.lo, self.hi,
+                                                  V.numpy()[:n], self._mask(term), self.lo, self.hi,
                                                   self.shape, self.strides, gamma, s_begin, s_end)
         policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
         self.calls["improve"] += 1
@@ -164,7 +168,7 @@ class OracleSweepBackend:
     def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta, d_changed):
         n = self.n
         _, new_pol, delta, changed = self.lib.value_sweep(
-            self.states, self.actions, policy.numpy()[:n], V.numpy()[:n], term.numpy()[:n], self.lo,
+            self.states, self.actions, policy.numpy()[:n], V.numpy()[:n], self._mask(term), self.lo,
             self.hi, self.shape, self.strides, gamma, s_begin, s_end, out=Vnew.numpy()[:n])
         policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
         if d_delta is not None:

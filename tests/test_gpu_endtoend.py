@@ -501,3 +501,68 @@ def test_plan_ranges_tile_the_shard_and_a_missing_peer_is_an_error_not_a_hang(cu
         cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device,
             transport=T.NativeTransport.local(0, 2, lonely))             # the plan's all-gather needs rank 1
     assert 1.5 < time.perf_counter() - t0 < 60.0
+
+
+@pytest.mark.parametrize("name,shape", [("pendulum", (64, 48)), ("pendulum", (200, 200)),
+                                         ("double_pendulum_swingup", (12, 9, 11, 17)), ("double_cartpole", (4, 3, 5, 3, 4, 6))])
+def test_null_mask_means_no_terminal_states(name, shape, cuda_device):
+    """term == NULL (what the solver passes for envs without terminal states: no mask stream, and no
+    old-value stream on sweeps without a residual) gives exactly what an all-zero mask gives: single
+    sweeps with and without a residual, batches (eager, graph and LDS-resident paths), improvement and
+    value sweeps, and the reach probe; and the solver really passes NULL for such envs and the tensor
+    for envs with terminal states."""
+    torch = _torch()
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    D = len(shape)
+    eng = _native.Engine(D, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0)
+    eng.compile(envs.dynamics_source(name))
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(9)
+    V = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(cuda_device)
+    pol = torch.from_numpy(rng.integers(0, len(acts), n).astype(np.int32)).to(cuda_device)
+    zero = torch.zeros(n, dtype=torch.uint8, device=cuda_device)
+    gamma = float(np.float32(0.97))
+
+    def run(mask_ptr):
+        out = {}
+        Vn = torch.full_like(V, float("nan"))
+        d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+        eng.eval_sweep(V.data_ptr(), Vn.data_ptr(), pol.data_ptr(), mask_ptr, 3, n - 2, gamma, d.data_ptr())
+        out["eval+res"] = (Vn.clone(), d.clone())
+        Vn2 = torch.full_like(V, float("nan"))
+        eng.eval_sweep(V.data_ptr(), Vn2.data_ptr(), pol.data_ptr(), mask_ptr, 0, n, gamma, 0)
+        out["eval"] = (Vn2,)
+        for sweeps in (3, 26):                                  # eager / resident and graph paths
+            a, b = V.clone(), torch.zeros_like(V)
+            eng.eval_sweeps(a.data_ptr(), b.data_ptr(), pol.data_ptr(), mask_ptr, 0, n, gamma, sweeps, d.data_ptr())
+            out[f"batch{sweeps}"] = (a, b, d.clone())
+        p2 = pol.clone()
+        c = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        eng.improve_sweep(V.data_ptr(), p2.data_ptr(), mask_ptr, 0, n, gamma, c.data_ptr())
+        out["improve"] = (p2, c.clone())
+        p3, Vv = pol.clone(), torch.zeros_like(V)
+        eng.value_sweep(V.data_ptr(), Vv.data_ptr(), p3.data_ptr(), mask_ptr, 0, n, gamma, d.data_ptr(), c.data_ptr())
+        out["value"] = (Vv, p3, d.clone(), c.clone())
+        p4, Vw = pol.clone(), torch.zeros_like(V)
+        eng.value_sweep(V.data_ptr(), Vw.data_ptr(), p4.data_ptr(), mask_ptr, 0, n, gamma, 0, 0)
+        out["value-noresidual"] = (Vw, p4)
+        bm = torch.zeros((shape[0] + 31) // 32, dtype=torch.int32, device=cuda_device)
+        eng.reach_planes(mask_ptr, 0, n // 2, bm.data_ptr(), dim=0)
+        out["reach"] = (bm,)
+        torch.cuda.synchronize()
+        return out
+
+    with_mask, without = run(zero.data_ptr()), run(0)
+    for key in with_mask:
+        for x, y in zip(with_mask[key], without[key]):
+            xa, ya = x.cpu().numpy(), y.cpu().numpy()
+            same = (xa.view(np.uint32 if xa.dtype.itemsize == 4 else np.uint8) == ya.view(np.uint32 if ya.dtype.itemsize == 4 else np.uint8))
+            assert same.all(), (key, int((~same).sum()))
+    eng.close()
+    s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cls.CONFIG), device=cuda_device)
+    has_terminals = bool(s.d_terminal_mask.any().item())
+    assert (s._mask_arg() is None) == (not has_terminals)
+    s._backend.close()
