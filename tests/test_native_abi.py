@@ -264,3 +264,37 @@ def test_inference_kernel_builds_without_a_gpu_and_validates_arguments(tmp_path)
         from utils.barycentric import DevicePolicy
         with pytest.raises(RuntimeError, match="ROCm GPU"):
             DevicePolicy(None, None, [0, 0], [1, 1], [3, 3], [3, 1], bits)
+
+
+def test_register_budgets_of_the_baseline_kernels(tmp_path):
+    """Occupancy cliffs the launch geometry depends on: the 80^4 evaluation kernel
+    runs 1 024-thread workgroups, two per CU — that needs 8 waves per SIMD, i.e. at most 64 VGPRs (at 65
+    only ONE such workgroup fits a CU and the sweep loses a fifth of its speed, profiles/r03/
+    negative_results.txt (8), (10)); the 6-D kernels must not spill.  Checked on the ahead-of-time build of
+    the same translation units the library hands to hipRTC."""
+    import subprocess
+    import __graft_entry__ as G
+    budgets = {("double_pendulum_swingup", 80): {"pi_eval_sweep_kernel": 64, "pi_improve_sweep_kernel": 96},
+               ("cartpole_swingup", 50): {"pi_eval_sweep_kernel": 64, "pi_improve_sweep_kernel": 96},
+               ("double_cartpole", 25): {"pi_eval_sweep_kernel": 128, "pi_improve_sweep_kernel": 168}}
+    for (name, bins), limits in budgets.items():
+        eng, dyn = G._engine_for(name, bins)
+        src = tmp_path / f"{name}.hip"
+        src.write_text(eng.kernel_source(dyn))
+        eng.close()
+        res = subprocess.run([G.HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "--genco",
+                              "-include", "hip/hip_runtime.h", "-Rpass-analysis=kernel-resource-usage", str(src),
+                              "-o", str(tmp_path / f"{name}.hsaco")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        usage, fn = {}, None
+        for line in res.stderr.splitlines():
+            if "Function Name:" in line:
+                fn = line.split("Function Name:")[1].split()[0]
+                usage[fn] = {}
+            elif fn and " VGPRs:" in line:
+                usage[fn]["vgpr"] = int(line.split("VGPRs:")[1].split()[0])
+            elif fn and "ScratchSize" in line:
+                usage[fn]["scratch"] = int(line.split(":")[-1].split()[0])
+        for kernel, limit in limits.items():
+            assert usage[kernel]["vgpr"] <= limit, (name, kernel, usage[kernel])
+            assert usage[kernel]["scratch"] == 0, (name, kernel, usage[kernel])
