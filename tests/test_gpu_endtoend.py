@@ -566,3 +566,31 @@ def test_null_mask_means_no_terminal_states(name, shape, cuda_device):
     has_terminals = bool(s.d_terminal_mask.any().item())
     assert (s._mask_arg() is None) == (not has_terminals)
     s._backend.close()
+
+
+def test_headline_sweep_times_stay_in_range(cuda_device):
+    """A coarse guard against performance cliffs on the metric config (double pendulum 80^4 x 11): the
+    evaluation sweep measured 0.40-0.43 ms and the improvement sweep 2.3-2.4 ms on MI355X (DESIGN.md section
+    5); one VGPR too many on the evaluation kernel alone costs ~20 % (one 1 024-thread workgroup per CU
+    instead of two).  Thresholds are a third above the measurements: a noisy box passes, a cliff does not."""
+    torch = _torch()
+    s = envs.make("double_pendulum_swingup", 80, device=cuda_device)
+    n, gamma = s.n_states, float(np.float32(s.config.gamma))
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    s.d_value_function[:n].copy_(torch.randn(n, generator=gen, dtype=torch.float32))
+    s.d_new_value_function.copy_(s.d_value_function)
+    s.d_policy[:n].copy_(torch.randint(0, s.n_actions, (n,), generator=gen, dtype=torch.int32))
+    s._evaluation_sweeps(10, gamma)
+    s._improvement_sweep(gamma)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    s._evaluation_sweeps(40, gamma)
+    e[1].record()
+    for _ in range(3):
+        s._improvement_sweep(gamma)
+    e[2].record()
+    e[2].synchronize()
+    eval_ms, improve_ms = e[0].elapsed_time(e[1]) / 40, e[1].elapsed_time(e[2]) / 3
+    s._backend.close()
+    assert eval_ms < 0.56, eval_ms
+    assert improve_ms < 3.2, improve_ms
