@@ -678,16 +678,16 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
             const bool want = k == n_sweeps - 1 && d_delta != nullptr;
             if (overlap) {
                 for (const auto& r : p->send_ranges)
-                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st, k >= 1)) return 1;
                 PI_HIP(hipEventRecord(p->ev_ready, st));
                 PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
                 if (post_exchange(h, dst, p->comm_stream)) return 1;
                 PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
                 for (const auto& r : p->interior)
-                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st)) return 1;
+                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st, k >= 1)) return 1;
                 PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
             } else {
-                if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st)) return 1;
+                if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st, k >= 1)) return 1;
                 if (pi_exchange_V(h, dst, stream)) return 1;
             }
         }

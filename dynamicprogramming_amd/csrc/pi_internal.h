@@ -93,8 +93,11 @@ int check_range(const pi_handle* h, int64_t s_begin, int64_t s_end);
 // One evaluation sweep over [s_begin, s_end) WITHOUT the finalize step: the residual stays in the
 // accumulator slots (want_delta) until finalize_delta is called, so several sub-range launches of
 // one logical sweep can share it.
+// keep_terminals: Vnew already holds the terminal states' values (every sweep of a ping-pong batch but the
+// first), so the sweep neither copies them nor streams old values for them.
 int launch_eval(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const uint8_t* term,
-                int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st);
+                int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st,
+                bool keep_terminals = false);
 int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
 // hipRTC (gfx950, -O3 -ffp-contract=off) or the on-disk code-object cache -> image of one translation unit

@@ -422,13 +422,17 @@ __device__ __forceinline__ void pi_store_lane(T* chunk_base, unsigned int lane, 
 }
 
 // ---- policy evaluation sweep ---------------------------------------------------
-// Vn[s] = r(s, pi(s)) + gamma * E[V](s')   for s in [s_begin, s_end); terminal: copy.
+// Vn[s] = r(s, pi(s)) + gamma * E[V](s')   for s in [s_begin, s_end); terminal: copy (keep_terminals != 0:
+// Vn holds the terminal values already — not stored, and their old values not read).
 // delta_bits (nullable): slots receiving the atomic max of the bit pattern of |Vn - V|.
-extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL)
+// At most 80 SGPRs: measured on MI355X, one SGPR allocation granule more (TotalSGPRs 84 .. 96) and only
+// seven waves fit a SIMD — the compiler still reports eight — so that ONE 1 024-thread workgroup is resident
+// per CU instead of two and the 80^4 sweep goes from 0.395 to 0.458 ms (profiles/r03/negative_results.txt (15)).
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL) __attribute__((amdgpu_num_sgpr(80)))
 pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
                      const int* __restrict__ policy, const unsigned char* __restrict__ term,
                      const float* __restrict__ tab, long long s_begin, long long s_end,
-                     float gamma, unsigned int* __restrict__ delta_bits, int cpw) {
+                     float gamma, unsigned int* __restrict__ delta_bits, int cpw, int keep_terminals) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
     if (!pi_first_chunk<PI_BLOCK_EVAL>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
@@ -438,7 +442,11 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
     long long sb = s_begin + chunk0 * PI_BLOCK_EVAL;                     // first state of the chunk
     // lanes past s_end (tail of the last chunk) shadow the last valid state and store nothing
     unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
-    const bool need_old = delta_bits != nullptr || term != nullptr;      // launch-uniform
+    // Old values are streamed when this launch reports a residual or has to copy the terminal states'
+    // values into Vn.  keep_terminals != 0 (every sweep of a ping-pong batch but the first): Vn already
+    // holds them — the first sweep copied them into one buffer out of the other — so terminal states are
+    // simply not stored and no old value is needed (launch-uniform).
+    const bool need_old = delta_bits != nullptr || (term != nullptr && keep_terminals == 0);
     PiStateIn nxt = pi_load_state(V, policy, term, sb, lane, need_old);
     pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
     __syncthreads();
@@ -469,7 +477,7 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
             }
             nv = reward + gamma * e;
         }
-        if (tid == lane_c) {
+        if (tid == lane_c && (need_old || !cur.term)) {
             pi_store_lane(Vn + sb_c, lane_c, nv);
             const float dlt = fabsf(nv - cur.v_old);
             dmax = dlt > dmax ? dlt : dmax;

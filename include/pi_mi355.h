@@ -95,6 +95,10 @@ int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* poli
  * two host checks (:305-331, SYNC_INTERVAL = 25).  d_delta (nullable) receives the
  * residual of the LAST sweep only, which is the only one the reference looks at.
  * The newest iterate is in Vb when n_sweeps is odd, in Va when even.
+ * Terminal states keep their value: sweep 0 copies it from Va into Vb, after which both buffers hold it
+ * and the later sweeps of the batch neither store it again nor stream the old values for it (without a
+ * residual request they read 5 B per state besides the gather instead of 9, and write only non-terminal
+ * states) — same values in both buffers as a copy on every sweep gives.
  * Ranges of up to 2^20 states are launch-bound (a few microseconds per sweep): there the whole
  * batch, including the residual fold, is replayed as ONE hipGraph (built on first use per
  * argument set, cached in the handle) instead of n_sweeps host launches.  Grids of up to 12 288

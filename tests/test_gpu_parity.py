@@ -168,15 +168,18 @@ def test_ragged_ranges_and_pingpong(name, shape, cuda_device):
                                     a, b, out=o_Vn)
         assert np.float32(d_delta.item()) == np.float32(o_delta), (a, b)
     H.assert_bits_equal(d_Vn.cpu().numpy(), o_Vn, "piecewise V'")
-    # 5 ping-pong sweeps == 5 oracle sweeps
-    d_A, d_B = d_V.clone(), torch.zeros_like(d_V)
+    # 5 ping-pong sweeps == 5 oracle sweeps, in BOTH buffers: Vb starts as NaN, the first sweep has to put the
+    # terminal states' values there, and the later ones (which no longer re-copy them) must leave them alone
+    d_A, d_B = d_V.clone(), torch.full_like(d_V, float("nan"))
     eng.eval_sweeps(d_A.data_ptr(), d_B.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n,
                     gamma, 5, d_delta.data_ptr())
     torch.cuda.synchronize()
-    cur = V
+    cur, prev = V, V
     for _ in range(5):
+        prev = cur
         cur, o_delta = chk.eval_sweep(states, acts, pol, cur, term, lo, hi, gshape, strides, gamma)
     H.assert_bits_equal(d_B.cpu().numpy(), cur, "5 ping-pong sweeps")
+    H.assert_bits_equal(d_A.cpu().numpy(), prev, "the iterate before (other buffer)")
     assert np.float32(d_delta.item()) == np.float32(o_delta)
     # piecewise improvement
     d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)

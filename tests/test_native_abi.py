@@ -270,8 +270,9 @@ def test_register_budgets_of_the_baseline_kernels(tmp_path):
     """Occupancy cliffs the launch geometry depends on: the 80^4 evaluation kernel
     runs 1 024-thread workgroups, two per CU — that needs 8 waves per SIMD, i.e. at most 64 VGPRs (at 65
     only ONE such workgroup fits a CU and the sweep loses a fifth of its speed, profiles/r03/
-    negative_results.txt (8), (10)); the 6-D kernels must not spill.  Checked on the ahead-of-time build of
-    the same translation units the library hands to hipRTC."""
+    negative_results.txt (8), (10)) AND at most 80 SGPRs (measured: at 84 .. 96 the same thing happens although
+    the compiler still reports eight waves, negative_results.txt (15)); the 6-D kernels must not spill.
+    Checked on the ahead-of-time build of the same translation units the library hands to hipRTC."""
     import subprocess
     import __graft_entry__ as G
     budgets = {("double_pendulum_swingup", 80): {"pi_eval_sweep_kernel": 64, "pi_improve_sweep_kernel": 96},
@@ -293,8 +294,11 @@ def test_register_budgets_of_the_baseline_kernels(tmp_path):
                 usage[fn] = {}
             elif fn and " VGPRs:" in line:
                 usage[fn]["vgpr"] = int(line.split("VGPRs:")[1].split()[0])
+            elif fn and "TotalSGPRs:" in line:
+                usage[fn]["sgpr"] = int(line.split("TotalSGPRs:")[1].split()[0])
             elif fn and "ScratchSize" in line:
                 usage[fn]["scratch"] = int(line.split(":")[-1].split()[0])
         for kernel, limit in limits.items():
             assert usage[kernel]["vgpr"] <= limit, (name, kernel, usage[kernel])
             assert usage[kernel]["scratch"] == 0, (name, kernel, usage[kernel])
+        assert usage["pi_eval_sweep_kernel"]["sgpr"] <= 80, (name, usage["pi_eval_sweep_kernel"])
