@@ -260,7 +260,9 @@ int pi_probe_coords(pi_handle* h, int64_t s_begin, int64_t s_end, float* out, in
  * caller's corner_bits table — itertools.product, MSB first, in the reference :233).  Independent of
  * pi_handle: needs no env plugin.
  *   pi_infer_create     host arrays; corner_bits is (n_corners = 2^D, D) int32 of 0/1; device = -1
- *                       builds the kernel only (compile check without a GPU); cache_dir as pi_compile
+ *                       builds the kernel only (compile check without a GPU); cache_dir as pi_compile.
+ *                       The grid and the corner table are compiled INTO the kernel (hipRTC, one code
+ *                       object per grid, cached on disk like the sweep kernels)
  *   pi_infer_set_policy host arrays: the greedy policy (n_states int32) and the action values; copied
  *                       to the device once, validated (every entry an index into action_space)
  *   pi_infer_query      d_points (m, D) float32 on the device; any of the three outputs may be null:
