@@ -656,6 +656,12 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 // depend on the action (in the double pendulum: all seven sin/cos and both angle wraps) is
 // hoisted out of it by the compiler; spreading the actions over lanes would redo that work
 // n_actions times.  The action values come from LDS.
+// Corner reuse across the action loop (below) pays where the action set is dense enough for neighbouring
+// actions to share cells, and costs registers: measured on MI355X 80^4 x 11 actions -4.7 %, 25^6 x 9 -3.5 %,
+// 50^4 x 5 and 200^2 x 21 unchanged, 25^6 x 3 +15 % (177 instead of 146 VGPRs: two waves per SIMD instead of three).
+#ifndef PI_IMPROVE_REUSE
+#define PI_IMPROVE_REUSE (PI_D >= 4 && PI_NA >= 8)
+#endif
 template <bool WRITE_V>
 __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, float* __restrict__ Vn,
                                                 int* __restrict__ policy,
@@ -695,10 +701,41 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
             pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
             float best_q = -1.0e30f;
             int best = 0;
+#if PI_IMPROVE_REUSE
+            // Neighbouring actions often land in the same cell (80^4: 41 % of consecutive pairs, 25^6 swing-up
+            // 43 %): the corner values of the cell the lane looked at last stay in registers and only lanes
+            // whose cell changed issue loads — the vector L1 charges per distinct line among the ACTIVE lanes
+            // of each lane quad (profiles/r03/negative_results.txt (16)).
+            PiPair vp[PI_NPAIR];
+#pragma unroll
+            for (int p = 0; p < PI_NPAIR; ++p) vp[p] = PiPair{0.0f, 0.0f};
+            unsigned int held = 0xffffffffu;
+            for (int a = 0; a < PI_NA; ++a) {
+                float ns[PI_D], reward;
+                bool done;
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
+                float e = 0.0f;
+                if (!done) {
+                    unsigned int base;
+                    float fr[PI_D];
+                    pi_locate(ns, base, fr);
+                    if (base != held) {
+                        pi_request_corners(V, base, vp);
+                        held = base;
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+                    e = pi_combine_corners(vp, fr);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                const float q = reward + gamma * e;
+                if (q > best_q) { best_q = q; best = a; }
+            }
+#else
             for (int a = 0; a < PI_NA; ++a) {
                 const float q = pi_backup(x, lds_tab[PI_TAB_ACT + a], V, gamma);
                 if (q > best_q) { best_q = q; best = a; }
             }
+#endif
             if (live) {
                 pi_store_lane(policy + sb_c, lane_c, best);
                 n_changed += (cur.action != best) ? 1u : 0u;
