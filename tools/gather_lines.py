@@ -50,6 +50,7 @@ def fit_shear():
 
 
 _shear = None
+quad_cost = []
 
 
 def wave_states(mapping, w):
@@ -82,6 +83,8 @@ def analyse(mapping, action_mode, n_waves=4000):
     total_waves = n // 64
     ws = rng.choice(total_waves, size=n_waves, replace=False)
     lines_per_load, cells = [], []
+    global quad_cost
+    quad_cost = []
     for w in ws:
         flat = wave_states(mapping, int(w))
         st, _ = coords_of(flat)
@@ -104,6 +107,8 @@ def analyse(mapping, action_mode, n_waves=4000):
             a0 = (base + o) // LINE
             a1 = (base + o + 1) // LINE
             per_load.append(len(set(a0.tolist()) | set(a1.tolist())))
+            # what the TCP charges (profiles/r03/negative_results.txt (16)): per 4-lane quad, its distinct lines
+            quad_cost.append(sum(len(set(a0[q:q + 4].tolist()) | set(a1[q:q + 4].tolist())) for q in range(0, 64, 4)))
         lines_per_load.append(np.mean(per_load))
         cells.append(len(set(base.tolist())))
     lp = np.array(lines_per_load)
@@ -114,4 +119,5 @@ for mapping in ["flat", "shear", "tile8x8", "tile4x16", "tile2x32", "tile16x4"]:
     for mode in ["bang", "random", "0.0"]:
         m, pct, cells = analyse(mapping, mode, 1500)
         print(f"{env}@{bins} mapping={mapping:9s} action={mode:6s}: lines per corner-pair load mean {m:5.1f} "
-              f"(p10/p50/p90 {pct[0]:.0f}/{pct[1]:.0f}/{pct[2]:.0f}), distinct cells per wave {cells:.1f}", flush=True)
+              f"(p10/p50/p90 {pct[0]:.0f}/{pct[1]:.0f}/{pct[2]:.0f}), distinct cells per wave {cells:.1f}, "
+              f"TCP look-ups per load (sum over quads of their lines) {np.mean(quad_cost):5.1f}", flush=True)
