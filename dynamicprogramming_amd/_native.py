@@ -72,9 +72,10 @@ SIGNATURES = {
     "pi_infer_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "pi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
+    "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 _load_error: Exception | None = None
 
@@ -208,6 +209,13 @@ class Engine:
 
     def info(self, what: int) -> int:
         return int(lib().pi_info(self._h, what))
+
+    def debug_report(self) -> dict:
+        """Checked build only (PI_MI355_DEBUG=1 when the engine was created): index violations of the sweeps
+        launched since the last report — {"violations", "kind" (1 policy entry, 2 cell), "where", "value"}."""
+        out = (ctypes.c_uint32 * 4)()
+        _check(lib().pi_debug_report(self._h, out), "pi_debug_report")
+        return {"violations": int(out[0]), "kind": int(out[1]), "where": int(out[2]), "value": int(out[3])}
 
     # -- launches (raw device pointers; all asynchronous on `stream`) ---------
     def eval_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta=0, stream=0):

@@ -75,6 +75,7 @@ struct pi_handle {
     int cpw_eval = 1, cpw_improve = 1;           // chunks a workgroup sweeps
     int vgpr_eval = -1, vgpr_improve = -1;
     bool cache_hit = false;
+    bool debug_bounds = false;           // PI_MI355_DEBUG=1 at pi_create: checked kernels (pi_debug_report)
     bool use_graphs = true;
     // LDS-resident evaluation batches (grids of up to ~12 k states): states per thread of the one
     // workgroup (resident_block threads), 0 = this grid is too big; the switch is pi_set_option 3

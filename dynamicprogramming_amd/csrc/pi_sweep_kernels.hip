@@ -133,6 +133,48 @@ __device__ __forceinline__ void pi_dynamics(const float (&s)[PI_D], float a, flo
 #endif
 }
 
+// ---- checked build (PI_DEBUG_BOUNDS) ----------------------------------------------------
+// PI_MI355_DEBUG=1 when the handle compiles its kernels: every index the sweeps derive from DATA — the
+// action a state's policy entry names, the cell a successor falls in — is checked before it is used,
+// a bad one is counted, remembered (the first: kind, flat state or cell, offending value) and replaced by
+// index 0, so that a corrupted policy array or a plugin bug shows up as a report (pi_debug_report) instead of
+// a wild read.  The GPU has no address sanitizer on this platform; the two-buffer Jacobi sweep is race-free
+// by construction (reference :321-323), which leaves indices as the thing to check.  Off (0): no code at all.
+#ifndef PI_DEBUG_BOUNDS
+#define PI_DEBUG_BOUNDS 0
+#endif
+#if PI_DEBUG_BOUNDS
+extern "C" __device__ unsigned int pi_debug_words[4] = {0u, 0u, 0u, 0u};   // faults | kind | where | value
+__device__ __forceinline__ void pi_debug_fault(unsigned int kind, unsigned int where, unsigned int value) {
+    if (atomicAdd(&pi_debug_words[0], 1u) == 0u) {
+        pi_debug_words[1] = kind;
+        pi_debug_words[2] = where;
+        pi_debug_words[3] = value;
+    }
+}
+#endif
+// kind 1: policy[s] is not an action index (where = s, value = the entry)
+__device__ __forceinline__ int pi_checked_action(int action, unsigned int s) {
+#if PI_DEBUG_BOUNDS
+    if ((unsigned int)action >= (unsigned int)PI_NA) {
+        pi_debug_fault(1u, s, (unsigned int)action);
+        return 0;
+    }
+#endif
+    (void)s;
+    return action;
+}
+// kind 2: a cell whose far corner lies outside the grid (where = the cell's flat index, value = 0)
+__device__ __forceinline__ unsigned int pi_checked_cell(unsigned int base) {
+#if PI_DEBUG_BOUNDS
+    if ((unsigned long long)base + (unsigned long long)pi_corner_offset(PI_C - 1) >= (unsigned long long)PI_GRID.n) {
+        pi_debug_fault(2u, base, 0u);
+        return 0u;
+    }
+#endif
+    return base;
+}
+
 // ---- interpolation ---------------------------------------------------------------
 // (s - lo) / (hi - lo) for every dimension.  Fast path: q = a * rcp is within an ulp of the
 // quotient, r = fma(-q, span, a) is the exact residual, fma(r, rcp, q) rounds to the IEEE
@@ -214,6 +256,7 @@ __device__ __forceinline__ void pi_locate(const float (&ns)[PI_D], unsigned int&
         for (int d = 0; d < PI_D; ++d)
             pi_cell_1d(a[d] / PI_SPAN[d] * (float)(PI_GRID.g[d] - 1), d, base, fr[d]);
     }
+    base = pi_checked_cell(base);
 }
 
 // The 2^D corner weights from the fractional offsets.  The reference multiplies
@@ -465,7 +508,7 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
         if (!cur.term) {
             float x[PI_D], ns[PI_D], reward;
             pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
-            const float a = lds_tab[PI_TAB_ACT + cur.action];
+            const float a = lds_tab[PI_TAB_ACT + pi_checked_action(cur.action, (unsigned int)sb_c + lane_c)];
             bool done;
             pi_dynamics(x, a, ns, &reward, &done);
             float e = 0.0f;
@@ -563,7 +606,7 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
                 float x[PI_D], ns[PI_D];
                 pi_state_coords(s, lds_tab, x);
                 bool done;
-                pi_dynamics(x, lds_tab[PI_TAB_ACT + policy[s]], ns, &reward[j], &done);
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + pi_checked_action(policy[s], s)], ns, &reward[j], &done);
                 kind[j] = 2u;
                 if (!done) {
                     pi_locate(ns, base[j], fr[j]);

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 3
+#define PI_MI355_ABI_VERSION 4
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -288,8 +288,21 @@ int pi_set_option(pi_handle* h, int what, int64_t value);
  * eval kernel, 5 VGPRs of the improve kernel, 6 compute units, 7 = 1 if the last pi_compile was
  * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
  * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
- * batch kernel (0: grid too big for it), 14 that kernel enabled, 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
+ * batch kernel (0: grid too big for it), 14 that kernel enabled, 15 checked kernels (pi_debug_report),
+ * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
+
+/*
+ * Checked build (sanitizer row: the reference has none; GPU address sanitizers are not
+ * available on this platform).  With PI_MI355_DEBUG=1 in the environment when pi_create runs, the handle's
+ * kernels check every index they derive from DATA before using it — the action a policy entry names
+ * (kind 1: where = flat state, value = the entry) and the cell a successor falls in (kind 2: where = the
+ * cell's flat index) — count violations, remember the first and carry on with index 0 instead of reading
+ * out of bounds.  pi_debug_report synchronises the device, copies {violations, kind, where, value} of the
+ * sweeps launched since the last report to out4 (host) and clears them; it fails on a handle built
+ * without the checks.  Results of a run without violations are those of the unchecked kernels.
+ */
+int pi_debug_report(pi_handle* h, uint32_t* out4);
 
 #ifdef __cplusplus
 }

@@ -568,6 +568,75 @@ def test_null_mask_means_no_terminal_states(name, shape, cuda_device):
     s._backend.close()
 
 
+@pytest.mark.parametrize("name,shape", [("pendulum", (64, 48)), ("pendulum", (200, 200)), ("cartpole", (9, 8, 11, 7)),
+                                         ("double_pendulum_swingup", (12, 9, 11, 17)), ("double_cartpole", (4, 3, 5, 3, 4, 6))])
+def test_checked_build_reports_bad_indices_and_changes_nothing_else(name, shape, cuda_device, monkeypatch, tmp_path):
+    """PI_MI355_DEBUG=1 (the sanitizer row of SURVEY section 5: checked kernels instead of an address sanitizer):
+    clean sweeps of every kind report no violation and give the unchecked kernels' bits; a policy array with
+    entries that are no action indices is REPORTED (count, first state, its value) and contained (the sweep
+    carries on with action 0 there instead of reading wild)."""
+    torch = _torch()
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    D = len(shape)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(21)
+    V = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(cuda_device)
+    pol = torch.from_numpy(rng.integers(0, len(acts), n).astype(np.int32)).to(cuda_device)
+    gamma = float(np.float32(0.97))
+
+    def engine():
+        e = _native.Engine(D, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                           device=cuda_device.index or 0)
+        e.compile(envs.dynamics_source(name), cache_dir=tmp_path)
+        return e
+
+    def sweeps(e, policy):
+        a, b = V.clone(), torch.full_like(V, float("nan"))
+        d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+        c = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        e.eval_sweeps(a.data_ptr(), b.data_ptr(), policy.data_ptr(), 0, 0, n, gamma, 4, d.data_ptr())   # resident / graph / eager
+        single = torch.full_like(V, float("nan"))
+        e.eval_sweep(V.data_ptr(), single.data_ptr(), policy.data_ptr(), 0, 0, n, gamma, 0)
+        p2 = policy.clone()
+        e.improve_sweep(V.data_ptr(), p2.data_ptr(), 0, 0, n, gamma, c.data_ptr())
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (a, b, d, single, p2, c)]
+
+    plain = engine()
+    assert plain.info(15) == 0
+    with pytest.raises(_native.NativeError, match="PI_MI355_DEBUG"):
+        plain.debug_report()
+    want = sweeps(plain, pol)
+    plain.close()
+    monkeypatch.setenv("PI_MI355_DEBUG", "1")
+    chk = engine()
+    assert chk.info(15) == 1 and "#define PI_DEBUG_BOUNDS 1" in chk.kernel_source(envs.dynamics_source(name))
+    got = sweeps(chk, pol)
+    assert chk.debug_report() == {"violations": 0, "kind": 0, "where": 0, "value": 0}
+    for x, y in zip(want, got):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    # corrupt three policy entries: an index one past the end, a negative one, a huge one
+    bad = pol.clone()
+    where = [5, n // 2, n - 3]
+    for s_, v_ in zip(where, (len(acts), -1, 1 << 30)):
+        bad[s_] = v_
+    single = torch.full_like(V, float("nan"))
+    chk.eval_sweep(V.data_ptr(), single.data_ptr(), bad.data_ptr(), 0, 0, n, gamma, 0)
+    rep = chk.debug_report()
+    assert rep["violations"] == 3 and rep["kind"] == 1 and rep["where"] in where
+    fixed = pol.clone()
+    for s_ in where:
+        fixed[s_] = 0                                           # what the checked kernel substitutes
+    ref = torch.full_like(V, float("nan"))
+    chk.eval_sweep(V.data_ptr(), ref.data_ptr(), fixed.data_ptr(), 0, 0, n, gamma, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(single.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+    assert chk.debug_report()["violations"] == 0                # cleared by the report before
+    chk.close()
+
+
 def test_headline_sweep_times_stay_in_range(cuda_device):
     """A coarse guard against performance cliffs on the metric config (double pendulum 80^4 x 11): the
     evaluation sweep measured 0.40-0.43 ms and the improvement sweep 2.3-2.4 ms on MI355X (DESIGN.md section

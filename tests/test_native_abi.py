@@ -134,6 +134,25 @@ def test_grids_beyond_32_bit_byte_offsets_compile(tmp_path):
     eng.close()
 
 
+def test_checked_build_compiles_for_gfx950(tmp_path, monkeypatch):
+    """PI_MI355_DEBUG=1: the kernels with index checks (include/pi_mi355.h, pi_debug_report) build for every D;
+    a handle without them refuses the report (run on hardware by tests/test_gpu_endtoend.py)."""
+    monkeypatch.setenv("PI_MI355_DEBUG", "1")
+    for name, shape in (("pendulum", (24, 17)), ("cartpole_swingup", (9, 7, 11, 5)), ("double_cartpole", (5, 4, 6, 4, 5, 4))):
+        eng = _host_engine(name, shape)
+        assert eng.info(15) == 1
+        eng.compile(envs.dynamics_source(name), cache_dir=tmp_path)
+        src = eng.kernel_source(envs.dynamics_source(name))
+        assert "#define PI_DEBUG_BOUNDS 1" in src
+        with pytest.raises(_native.NativeError, match="host-only"):
+            eng.debug_report()
+        eng.close()
+    monkeypatch.delenv("PI_MI355_DEBUG")
+    eng = _host_engine("pendulum", (24, 17))
+    assert eng.info(15) == 0 and "#define PI_DEBUG_BOUNDS 1" not in eng.kernel_source(envs.dynamics_source("pendulum"))
+    eng.close()
+
+
 def test_no_gpu_means_runtime_error_not_fallback():
     """Without a GPU the product refuses to construct a solver (reference :71-75 raises for a
     missing CuPy); it must not quietly compute on the CPU."""
