@@ -1,6 +1,7 @@
 """tools/full_run.py env bins — one full run() to convergence with progress on stderr; prints sweeps, seconds and digests of V / policy."""
 import logging, sys, time, json
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 logging.basicConfig(level=logging.INFO, stream=sys.stderr, format="%(asctime)s %(message)s")
 import torch
 from dynamicprogramming_amd import envs
