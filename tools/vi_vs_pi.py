@@ -5,7 +5,8 @@ Policy iteration = the reference's run() (evaluation sweeps to theta, then one i
 is stable).  Value iteration = solver.value_iteration(): V' = max_a Q and the argmax in ONE kernel per sweep until
 the residual (looked at every 25 sweeps) is below the same theta.  A value-iteration sweep costs what an improvement
 sweep costs (n_actions backups per state); an evaluation sweep costs one backup per state.
-usage: python tools/vi_vs_pi.py env@bins [env@bins ...]   (default: pendulum@200 cartpole_swingup@50)
+usage: python tools/vi_vs_pi.py [--vi-only] env@bins [env@bins ...]   (default: pendulum@200 cartpole_swingup@50)
+--vi-only: value iteration alone (grids whose policy iteration does not fit one GPU call), progress on stderr.
 """
 import json
 import sys
@@ -20,7 +21,25 @@ from dynamicprogramming_amd import envs
 
 cases = [(a, int(b)) for a, b in (x.split("@") for x in sys.argv[1:] if "@" in x)] or \
     [("pendulum", 200), ("cartpole_swingup", 50)]
+VI_ONLY = "--vi-only" in sys.argv
 for name, bins in cases:
+    if VI_ONLY:
+        vi = envs.make(name, bins)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, delta = 0, float("inf")
+        while total < 400_000 and not delta < vi.config.theta:
+            delta = vi.value_iteration(max_iter=500)         # 500-sweep slices: a progress line each
+            total = vi.stats["value_sweeps"]
+            print(f"{name}@{bins}: {total} sweeps, residual {delta:.3e}, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        t_vi = time.perf_counter() - t0
+        print(json.dumps({"grid": f"{name} {bins}^{vi._D}", "states": vi.n_states, "actions": vi.n_actions,
+                          "theta": vi.config.theta, "gamma": vi.config.gamma,
+                          "value_iteration": {"sweeps": total, "last_residual": delta, "converged": bool(delta < vi.config.theta),
+                                              "seconds": round(t_vi, 3), "backups": vi.n_states * vi.n_actions * total,
+                                              "backups_per_s": vi.n_states * vi.n_actions * total / t_vi}}), flush=True)
+        continue
     pi = envs.make(name, bins)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
