@@ -118,3 +118,15 @@ def test_committed_bench_evidence_matches_the_kernels_and_the_contract():
     if stale:
         pytest.skip(f"kernels changed since {latest.name} was made ({', '.join(stale)}): "
                     "re-run tools/refresh_profiles.sh on a GPU box")
+
+
+def test_tools_parse_and_name_only_existing_entry_points():
+    """tools/*.py are run on GPU boxes only; here they must at least parse, and every attribute they take
+    from the ctypes layer must exist there (a renamed Engine method would otherwise surface mid-profile)."""
+    import ast
+    from dynamicprogramming_amd import _native
+    for path in sorted((ROOT / "tools").glob("*.py")):
+        tree = ast.parse(path.read_text(), filename=str(path))
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "_native":
+                assert hasattr(_native, node.attr), f"{path.name}: _native.{node.attr} does not exist"
