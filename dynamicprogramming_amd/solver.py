@@ -466,6 +466,12 @@ class _CudaPolicyIterationBase(abc.ABC):
         self.stats["value_sweeps"] = self.stats.get("value_sweeps", 0) + sweeps
         return delta
 
+    def debug_report(self) -> dict:
+        """Checked build only (PI_MI355_DEBUG=1 in the environment when the solver was constructed): the
+        index violations its sweeps found since the last report — {"violations", "kind", "where", "value"}
+        (include/pi_mi355.h, pi_debug_report).  Raises on a solver whose kernels carry no checks."""
+        return self._backend.engine.debug_report()
+
     def save_checkpoint(self, filepath) -> None:
         """Mid-run snapshot (V, policy, counters) that `load_checkpoint` can resume from; the
         reference can only save after run() has dropped its device arrays (:392-409).  Collective

@@ -635,6 +635,13 @@ def test_checked_build_reports_bad_indices_and_changes_nothing_else(name, shape,
     assert np.array_equal(single.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
     assert chk.debug_report()["violations"] == 0                # cleared by the report before
     chk.close()
+    if name == "cartpole":                                      # and through the solver API, on a real env run
+        solver = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**{**cls.CONFIG, "max_pi_iter": 2,
+                                                                                       "max_eval_iter": 60}), device=cuda_device)
+        solver.policy_evaluation()
+        solver.policy_improvement()
+        assert solver.debug_report()["violations"] == 0
+        solver._backend.close()
 
 
 def test_headline_sweep_times_stay_in_range(cuda_device):
