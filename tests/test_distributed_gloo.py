@@ -84,3 +84,59 @@ def test_sharded_run_is_bit_identical_to_single_rank(world, name, shape, exchang
         else:                                                        # boundary + interior launches
             assert int(got["evals"]) >= single.stats["eval_sweeps"]
         assert (int(got["halo"]) >= 0) == (exchange == "halo")
+
+
+def _worker_vi(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, out_dir: str, exchange: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    import os
+    os.environ["PI_MI355_EXCHANGE"] = exchange
+    os.environ["PI_MI355_POISON_UNREACHED"] = "1"
+    import torch
+    import torch.distributed as dist
+    from dynamicprogramming_amd import envs
+    from dynamicprogramming_amd.solver import CudaPIConfig
+    from tests import helpers as H
+    from tests.dist_transport import TorchDistTransport
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        cls = envs.ENVS[name]
+        make = lambda: H.with_checker_backend(cls)(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw),
+                                                   transport=TorchDistTransport())
+        s = make()
+        delta = s.value_iteration(max_iter=31)               # residual looked at on sweeps 0, 25 and 30
+        s.save_checkpoint(Path(out_dir) / "vi_ckpt")          # collective: rank 0 writes
+        dist.barrier()
+        r = make()                                            # every rank resumes from rank 0's file
+        r.load_checkpoint(Path(out_dir) / "vi_ckpt")
+        delta2 = r.value_iteration(max_iter=7)
+        r._pull_tensors_from_gpu()
+        np.savez(Path(out_dir) / f"vi_rank{rank}.npz", V=r.value_function, policy=r.policy,
+                 deltas=np.asarray([delta, delta2], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
+@pytest.mark.parametrize("world,name,shape", [(2, "cartpole", (9, 4, 7, 3)), (3, "pendulum", (31, 13))])
+def test_sharded_value_iteration_and_checkpoint_resume(world, name, shape, exchange, tmp_path):
+    """The 'next' rows of SURVEY section 8f.4 on several ranks: fused value-iteration sweeps with the exchange
+    after every sweep, a collective checkpoint written by rank 0, every rank resuming from it — bit-identical
+    to one rank doing 31 + 7 sweeps without a break."""
+    import torch.multiprocessing as mp
+    from dynamicprogramming_amd import envs
+    from dynamicprogramming_amd.solver import CudaPIConfig
+    from tests import helpers as H
+    cfg_kw = {**envs.ENVS[name].CONFIG, "theta": 1e-30}       # never converges early: sweep counts are exact
+    mp.spawn(_worker_vi, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path), exchange),
+             nprocs=world, join=True)
+    cls = envs.ENVS[name]
+    single = H.with_checker_backend(cls)(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw))
+    d1 = single.value_iteration(max_iter=31)
+    d2 = single.value_iteration(max_iter=7)
+    single._pull_tensors_from_gpu()
+    for r in range(world):
+        got = np.load(tmp_path / f"vi_rank{r}.npz")
+        H.assert_bits_equal(got["V"], single.value_function, f"rank {r} V")
+        assert np.array_equal(got["policy"], single.policy)
+        assert got["deltas"].tolist() == [d1, d2]

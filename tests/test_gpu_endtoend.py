@@ -644,6 +644,62 @@ def test_checked_build_reports_bad_indices_and_changes_nothing_else(name, shape,
         solver._backend.close()
 
 
+@pytest.mark.parametrize("mode", ["halo", "allgather"])
+@pytest.mark.parametrize("world,name,shape", [(2, "cartpole", (9, 8, 11, 7)), (4, "double_pendulum_swingup", (16, 6, 8, 6))])
+def test_sharded_value_iteration_and_checkpoint_on_the_native_transport(world, name, shape, mode, cuda_device,
+                                                                        monkeypatch, tmp_path):
+    """Rows f4 + e together through the C++ transport (in-process form, `world` logical ranks on one GPU): fused
+    value-iteration sweeps with pi_exchange_V after every sweep, a collective checkpoint written by rank 0, every
+    rank resuming from it — bit-identical to one rank doing 31 + 7 sweeps (tests/test_distributed_gloo.py runs
+    the same scenario over gloo with the CPU checker)."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_EXCHANGE", mode)
+    cls = envs.ENVS[name]
+    cfg = dict(cls.CONFIG, theta=1e-30)
+    make = lambda **kw: cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg), device=cuda_device, **kw)
+    single = make()
+    d1 = single.value_iteration(max_iter=31)
+    d2 = single.value_iteration(max_iter=7)
+    single._pull_tensors_from_gpu()
+    groups = [f"vi-{uuid.uuid4().hex}", f"vi-{uuid.uuid4().hex}"]
+    barrier = threading.Barrier(world)
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            stream = torch.cuda.Stream(device=cuda_device)
+            with torch.cuda.stream(stream):
+                s = make(transport=T.NativeTransport.local(r, world, groups[0]))
+                a = s.value_iteration(max_iter=31)
+                s.save_checkpoint(tmp_path / "ckpt")
+                stream.synchronize()
+                barrier.wait(timeout=120)
+                t = make(transport=T.NativeTransport.local(r, world, groups[1]))
+                t.load_checkpoint(tmp_path / "ckpt")
+                b = t.value_iteration(max_iter=7)
+                t._pull_tensors_from_gpu()
+            out[r] = (t.value_function, t.policy, a, b)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(o is not None for o in out), "a rank did not finish"
+    for r in range(world):
+        V, pol, a, b = out[r]
+        H.assert_bits_equal(V, single.value_function, f"rank {r} V")
+        assert np.array_equal(pol, single.policy)
+        assert (a, b) == (d1, d2)
+
+
 def test_headline_sweep_times_stay_in_range(cuda_device):
     """A coarse guard against performance cliffs on the metric config (double pendulum 80^4 x 11): the
     evaluation sweep measured 0.40-0.43 ms and the improvement sweep 2.3-2.4 ms on MI355X (DESIGN.md section
