@@ -860,6 +860,21 @@ def test_runner_script_end_to_end(cuda_device, tmp_path):
     res2 = subprocess.run(cmd[:2] + ["--save-path", str(out)], capture_output=True, text=True, timeout=300,
                           cwd=tmp_path)
     assert res2.returncode == 0 and "Loading existing policy" in res2.stdout
+    # extension flag: the same command line with --value-iteration writes the same archive schema, holding the
+    # fixed point of the fused max-backup sweep (what solver.value_iteration() converges to)
+    out_vi = tmp_path / "vi_policy.npz"
+    res3 = subprocess.run(cmd[:2] + ["--bins", "50", "--retrain", "--value-iteration", "--save-path", str(out_vi)],
+                          capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert res3.returncode == 0 and "value iteration:" in res3.stdout and "converged=True" in res3.stdout, res3.stdout + res3.stderr
+    v = np.load(out_vi)
+    assert set(v.files) == set(want) and all(v[k].dtype == t for k, t in want.items())
+    direct = envs.make("pendulum", 50)
+    while not direct.value_iteration() < direct.config.theta:
+        pass
+    direct._pull_tensors_from_gpu()
+    H.assert_bits_equal(v["value_function"], direct.value_function, "runner --value-iteration vs solver.value_iteration()")
+    assert np.array_equal(v["policy"], direct.policy)
+    assert np.mean(v["policy"] == d["policy"]) > 0.99 and np.abs(v["value_function"] - d["value_function"]).max() < 0.05
 
 
 def test_rccl_entry_points_world_1(cuda_device):

@@ -178,6 +178,8 @@ def test_runner_cli_accepts_the_reference_flag_set(name):
                       "--bins", "12", "--seed", "7", "--no-plot", "--retrain", "--save-path", "x/y.npz"])
     assert a.random == 5 and a.bins == 12 and a.retrain and str(a.record) == "out.gif"
     assert p.parse_args(["--random", "9"]).random == 9
+    # the one extension flag: off by default, so a reference command line trains with policy iteration
+    assert d.value_iteration is False and p.parse_args(["--value-iteration"]).value_iteration is True
     if name == "overhead_crane":
         c = p.parse_args(["--target-x", "0.0", "--start-x", "1.5"])
         assert (c.target_x, c.start_x) == (0.0, 1.5) and p.parse_args([]).target_x == -2.5
