@@ -700,6 +700,51 @@ def test_sharded_value_iteration_and_checkpoint_on_the_native_transport(world, n
         assert (a, b) == (d1, d2)
 
 
+def test_handles_give_their_device_memory_back(cuda_device):
+    """pi_destroy / pi_infer_destroy / pi_comm_destroy release everything the library allocated itself (bin tables,
+    accumulator slots, graphs, code objects, policy tables, in-process transport state): 60 create-use-destroy cycles
+    leave the device's free memory where it was."""
+    import uuid
+    from itertools import product
+    torch = _torch()
+    name, shape = "cartpole_swingup", (14, 9, 12, 8)
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    n = int(np.prod(shape))
+    V = torch.zeros(n, dtype=torch.float32, device=cuda_device)
+    Vn = torch.zeros_like(V)
+    pol = torch.zeros(n, dtype=torch.int32, device=cuda_device)
+    d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    bits = np.array(list(product([0, 1], repeat=4)), dtype=np.int32)
+    strides = [int(np.prod(shape[k + 1:])) for k in range(4)]
+    policy_host = np.zeros(n, np.int32)
+
+    def cycle():
+        eng = _native.Engine(4, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                             device=cuda_device.index or 0)
+        eng.compile(envs.dynamics_source(name))
+        eng.comm_init_local(0, 1, f"leak-{uuid.uuid4().hex}")
+        eng.eval_sweeps(V.data_ptr(), Vn.data_ptr(), pol.data_ptr(), 0, 0, n, 0.99, 26, d.data_ptr())    # a cached graph
+        eng.improve_sweep(V.data_ptr(), pol.data_ptr(), 0, 0, n, 0.99, 0)
+        torch.cuda.synchronize()
+        eng.close()
+        inf = _native.InferenceEngine([b.min() for b in bins], [b.max() for b in bins], list(shape), strides, bits,
+                                      device=cuda_device.index or 0)
+        inf.set_policy(policy_host, acts)
+        inf.close()
+
+    for _ in range(3):
+        cycle()                                                  # warm the allocator pools and the caches
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(cuda_device)
+    for _ in range(60):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(cuda_device)
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB not returned after 60 handle cycles"
+
+
 def test_headline_sweep_times_stay_in_range(cuda_device):
     """A coarse guard against performance cliffs on the metric config (double pendulum 80^4 x 11): the
     evaluation sweep measured 0.40-0.43 ms and the improvement sweep 2.3-2.4 ms on MI355X (DESIGN.md section
