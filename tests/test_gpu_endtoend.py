@@ -382,6 +382,13 @@ def test_device_inference_matches_the_reference_function(cuda_device):
         for c in range(1 << D):                                    # ascending corners, multiply then add
             seq = seq + wn[:, c] * actions[policy[idxn[:, c]]]
         H.assert_bits_equal(dp(big), seq, f"D={D} device action")
+        # states already on the device: a device tensor comes back, same bits, no host round trip
+        d_big = _torch().from_numpy(big).to(cuda_device)
+        d_act = dp(d_big)
+        assert _torch().is_tensor(d_act) and d_act.device == d_big.device
+        H.assert_bits_equal(d_act.cpu().numpy(), seq, f"D={D} device action from a device tensor")
+        with pytest.raises(ValueError, match="float32"):
+            dp(d_big.double())
         # a permuted corner table is honoured (the reference takes corner_bits as an argument)
         perm = rng.permutation(1 << D)
         dq = DevicePolicy(policy, actions, lo, hi, gshape, strides, bits[perm], device=cuda_device)

@@ -54,13 +54,22 @@ class DevicePolicy:
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
 
-    def __call__(self, states) -> np.ndarray:
+    def __call__(self, states):
+        """states (m, D): a numpy array -> numpy actions (m,), or a float32 torch tensor already on this
+        device -> a torch tensor on the device (no host round trip: closed-loop rollouts on the GPU)."""
         if not self._has_policy:
             raise RuntimeError("this DevicePolicy was built without a policy table")
-        d_pts, m = self._points(states)
+        on_device = self._torch.is_tensor(states)
+        if on_device:
+            if states.device != self.device or states.dtype != self._torch.float32 or states.dim() != 2 \
+                    or states.shape[1] != self.D:
+                raise ValueError(f"device states must be a float32 (m, {self.D}) tensor on {self.device}")
+            d_pts, m = states.contiguous(), states.shape[0]
+        else:
+            d_pts, m = self._points(states)
         out = self._torch.empty(m, dtype=self._torch.float32, device=self.device)
         self._engine.query(d_pts.data_ptr(), m, d_actions=out.data_ptr(), stream=self._stream())
-        return out.cpu().numpy()
+        return out if on_device else out.cpu().numpy()
 
     def weights_and_indices(self, states):
         d_pts, m = self._points(states)
