@@ -707,6 +707,76 @@ def test_sharded_value_iteration_and_checkpoint_on_the_native_transport(world, n
         assert (a, b) == (d1, d2)
 
 
+def _closed_loop(name, bins, start, steps, cuda_device, m=4096):
+    """Train `name` on its reference grid with run(), then drive m states in closed loop entirely on the GPU: the
+    interpolated action from the batched inference kernel (DevicePolicy on device tensors), the env step from the
+    plugin's own step_dynamics (pi_probe_step).  Returns (final states, ever-terminated flags, rewards of the
+    last 50 steps)."""
+    torch = _torch()
+    from utils.barycentric import DevicePolicy
+    cls = envs.ENVS[name]
+    solver = envs.make(name, bins)
+    solver.run()                                               # releases its device arrays and its handle
+    assert solver.stats["stable"] or name == "pendulum"        # pendulum 200^2 stops at max_pi_iter, as the reference does
+    tabs = [np.asarray(b, np.float32) for b in cls.bins_space(bins).values()]
+    D = len(tabs)
+    eng = _native.Engine(D, [len(t) for t in tabs], [t.min() for t in tabs], [t.max() for t in tabs], tabs,
+                         solver.action_space, device=cuda_device.index or 0)
+    eng.compile(envs.dynamics_source(name))                    # the env step of the rollout: the plugin itself
+    dp = DevicePolicy(solver.policy, solver.action_space, solver.bounds_low, solver.bounds_high, solver.grid_shape,
+                      solver.strides, solver.corner_bits, device=cuda_device)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    states = start(torch.rand((m, D), generator=gen), solver).to(torch.float32).to(cuda_device)
+    nxt = torch.empty_like(states)
+    rew = torch.empty(m, dtype=torch.float32, device=cuda_device)
+    done = torch.empty(m, dtype=torch.uint8, device=cuda_device)
+    ended = torch.zeros(m, dtype=torch.bool, device=cuda_device)
+    tail = torch.zeros(m, dtype=torch.float32, device=cuda_device)
+    st = torch.cuda.current_stream(cuda_device).cuda_stream
+    for t in range(steps):
+        act = dp(states)
+        assert act.device == states.device
+        eng.probe_step(states.data_ptr(), act.data_ptr(), nxt.data_ptr(), rew.data_ptr(), done.data_ptr(), m, st)
+        ended |= done != 0
+        states, nxt = nxt, states
+        if t >= steps - 50:
+            tail += rew
+    torch.cuda.synchronize()
+    dp.close()
+    eng.close()
+    return states, ended, tail / 50
+
+
+def test_trained_policies_solve_their_tasks_in_closed_loop(cuda_device):
+    """What the reference uses in place of tests (rollouts of the learned policy on the real env,
+    e.g. pendulum_cuda.py:151-177, cartpole_cuda.py:163-191): an end-to-end check that the solver produces policies
+    that SOLVE the tasks, not only bits that match the oracle's.
+      Pendulum 200^2        4 096 states anywhere on the grid -> upright and still after 400 steps
+      CartPole 30^4         gymnasium's start (all coordinates within +-0.05) -> no termination in 500 steps (CartPole-v1's bar)
+      CartPole swing-up 50^4  pole hanging DOWN -> swung up, balanced, cart on the track after 1 000 steps"""
+    torch = _torch()
+
+    def anywhere(u, solver):
+        lo, hi = torch.tensor(solver.bounds_low), torch.tensor(solver.bounds_high)
+        return lo + (hi - lo) * u
+    states, _, cost = _closed_loop("pendulum", 200, anywhere, 400, cuda_device)
+    upright = ((states[:, 0].abs() < 0.1) & (states[:, 1].abs() < 0.5)).float().mean().item()
+    assert upright >= 0.97, f"only {upright:.3f} of the pendulums end upright"
+    assert cost.mean().item() > -0.05                          # gymnasium's cost: ~0 when balanced
+
+    states, ended, _ = _closed_loop("cartpole", 30, lambda u, s: (u * 2 - 1) * 0.05, 500, cuda_device)
+    assert not ended.any().item(), f"{int(ended.sum())} of {len(ended)} cart-poles fell within 500 steps"
+
+    def hanging(u, solver):
+        x = (u * 2 - 1) * 0.05
+        x[:, 2] += float(np.pi)
+        return x
+    states, ended, _ = _closed_loop("cartpole_swingup", 50, hanging, 1000, cuda_device)
+    theta = torch.atan2(torch.sin(states[:, 2]), torch.cos(states[:, 2])).abs()
+    up = ((theta < 0.05) & (states[:, 3].abs() < 0.1) & ~ended).float().mean().item()
+    assert up >= 0.99, f"only {up:.3f} of the poles were swung up and held"
+
+
 def test_handles_give_their_device_memory_back(cuda_device):
     """pi_destroy / pi_infer_destroy / pi_comm_destroy release everything the library allocated itself (bin tables,
     accumulator slots, graphs, code objects, policy tables, in-process transport state): 60 create-use-destroy cycles
