@@ -1,9 +1,9 @@
-// tests/native/host_asan_driver.cpp — the host side of libpi_mi355 under AddressSanitizer + UBSan (CPU only).
+// tools/native/host_asan_driver.cpp — the host side of libpi_mi355 under AddressSanitizer + UBSan (CPU only).
 //
 // GPU sanitizers do not exist on this platform (sanitizer row), so the device side has
 // the checked build (PI_MI355_DEBUG=1) and the HOST side — handles, source generation, hipRTC plumbing,
 // the exchange planner, argument validation — is compiled from its sources with the address and undefined-behaviour sanitizers
-// into this driver by tests/test_native_abi.py and run without a GPU (device = -1 handles).  Any report
+// into this driver by tools/host_sanitizer_check.py and run without a GPU (device = -1 handles).  Any report
 // makes the process exit non-zero.
 #include "pi_mi355.h"
 
