@@ -235,6 +235,9 @@ def main() -> None:
                     help="skip the run of policy iteration to convergence from V = 0 (the metric's "
                          "'sweeps-to-converge' part: sweeps, outer iterations, wall time; ~45 s on C4, "
                          "N = 1 only, outside the timed region)")
+    ap.add_argument("--full-run", action="store_true",
+                    help="run to convergence even on grids of 2^27 states or more, where it takes minutes "
+                         "(25^6: 263 s, profiles/r03/full_runs.txt) and is skipped by default")
     ap.add_argument("--cpu-sample", type=int, default=1 << 26,
                     help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
                          "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
@@ -350,7 +353,9 @@ def main() -> None:
 
     # ── sweeps-to-converge (optional: a full run() from V = 0 with the env's own settings) ───
     full_run = None
-    if world == 1 and not args.no_full_run:
+    if world == 1 and not args.no_full_run and n >= (1 << 27) and not args.full_run:
+        full_run = {"skipped": f"{n} states: a run to convergence takes minutes; pass --full-run"}
+    elif world == 1 and not args.no_full_run:
         try:
             fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
             torch.cuda.synchronize()
