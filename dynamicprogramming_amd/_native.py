@@ -73,9 +73,10 @@ SIGNATURES = {
     "pi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
     "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "pi_prepare_mask": (ctypes.c_int, [_vp, _vp, _vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 _load_error: Exception | None = None
 
@@ -209,6 +210,12 @@ class Engine:
 
     def info(self, what: int) -> int:
         return int(lib().pi_info(self._h, what))
+
+    def prepare_mask(self, term, stream=0) -> int:
+        """Let later sweeps of whole-grid batches visit only the non-terminal states of the mask at `term`
+        (0 drops the list); returns the number of live states listed, 0 when the library keeps none."""
+        _check(lib().pi_prepare_mask(self._h, term or None, stream or None), "pi_prepare_mask")
+        return self.info(16)
 
     def debug_report(self) -> dict:
         """Checked build only (PI_MI355_DEBUG=1 when the engine was created): index violations of the sweeps

@@ -67,7 +67,7 @@ struct pi_handle {
     float* d_tab = nullptr;
     unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed
     hipModule_t module = nullptr;
-    hipFunction_t f_eval = nullptr, f_improve = nullptr, f_value = nullptr, f_finalize = nullptr,
+    hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr, f_resident = nullptr;
     int num_cu = 0;
@@ -83,6 +83,11 @@ struct pi_handle {
     bool use_resident = true;
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;
+    // pi_prepare_mask: the non-terminal states of the mask at live_term, ascending (device, owned); in use only
+    // when visiting them instead of all states saves enough idle lanes (live_count > 0)
+    const uint8_t* live_term = nullptr;
+    int32_t* d_live = nullptr;
+    int64_t live_count = 0;
     pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank
     pi::ShardPlan* plan = nullptr;       // exchange plan (owned; pi_comm.cpp)
 };

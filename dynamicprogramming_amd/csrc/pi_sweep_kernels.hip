@@ -529,6 +529,83 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
     if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
 }
 
+// ---- policy evaluation sweep over the LIVE states only -----------------------------------
+// Grids with many terminal states (double cartpole 25^6: 35 %) leave lanes idle in every wave that straddles the
+// border of a terminal region (16 % of that grid's waves), and an idle lane costs its wave's gather as much as a
+// busy one (the vector L1 charges per instruction and quad).  `live` lists the non-terminal states in ascending
+// order (built once per mask by the host: pi_prepare_mask); lane k of the launch takes state live[k], so every
+// wave is full.  Only for sweeps that do not have to copy terminal values (keep_terminals of
+// pi_eval_sweep_kernel: every sweep of a batch but the first) — terminal states are simply not visited; their
+// residual contribution is 0 by definition.  Same arithmetic per state, hence the same bits.  The list index is
+// fetched two chunks ahead and the state's inputs one chunk ahead, so the dependent load is off the critical path.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL) __attribute__((amdgpu_num_sgpr(80)))
+pi_eval_live_kernel(const float* __restrict__ V, float* __restrict__ Vn, const int* __restrict__ policy,
+                    const int* __restrict__ live, const float* __restrict__ tab, long long n_live, float gamma,
+                    unsigned int* __restrict__ delta_bits, int cpw) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk<PI_BLOCK_EVAL>(n_live, cpw, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    const unsigned int tid = threadIdx.x;
+    const long long kb0 = chunk0 * PI_BLOCK_EVAL;                       // first list entry of the workgroup
+    const bool need_old = delta_bits != nullptr;                        // launch-uniform
+    // lanes past the end of the list (tail of the last chunk) shadow its last entry and store nothing
+    auto lane_of = [&](int k) {
+        return min(tid, (unsigned int)(min(n_live - (kb0 + (long long)k * PI_BLOCK_EVAL), (long long)PI_BLOCK_EVAL) - 1));
+    };
+    auto entry = [&](int k, unsigned int lane) {
+        return (unsigned int)__builtin_nontemporal_load(pi_lane_ptr(live + kb0 + (long long)k * PI_BLOCK_EVAL, lane));
+    };
+    unsigned int lane_cur = lane_of(0);
+    unsigned int s_cur = entry(0, lane_cur);
+    unsigned int lane_nxt = lane_cur, s_nxt = s_cur;
+    if (n_here > 1) {
+        lane_nxt = lane_of(1);
+        s_nxt = entry(1, lane_nxt);
+    }
+    int a_cur = __builtin_nontemporal_load(policy + s_cur);
+    float v_cur = 0.0f;
+    if (need_old) v_cur = V[s_cur];
+    pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
+    __syncthreads();
+
+    float dmax = 0.0f;
+    for (int k = 0; k < n_here; ++k) {
+        const unsigned int s = s_cur, lane_c = lane_cur;
+        const int action = a_cur;
+        const float v_old = v_cur;
+        if (k + 1 < n_here) {                                           // inputs of the next chunk; index of the one after
+            s_cur = s_nxt;
+            lane_cur = lane_nxt;
+            a_cur = __builtin_nontemporal_load(policy + s_cur);
+            if (need_old) v_cur = V[s_cur];
+            if (k + 2 < n_here) {
+                lane_nxt = lane_of(k + 2);
+                s_nxt = entry(k + 2, lane_nxt);
+            }
+        }
+        float x[PI_D], ns[PI_D], reward;
+        pi_state_coords(s, lds_tab, x);
+        const float a = lds_tab[PI_TAB_ACT + pi_checked_action(action, s)];
+        bool done;
+        pi_dynamics(x, a, ns, &reward, &done);
+        float e = 0.0f;
+        if (!done) {
+            unsigned int base;
+            float fr[PI_D];
+            pi_locate(ns, base, fr);
+            e = pi_interpolate(V, base, fr);
+        }
+        const float nv = reward + gamma * e;
+        if (tid == lane_c) {
+            Vn[s] = nv;
+            const float dlt = fabsf(nv - v_old);
+            dmax = dlt > dmax ? dlt : dmax;
+        }
+    }
+    if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
+}
+
 // ---- LDS-resident evaluation batch for small grids ----------------------------------------
 // Grids of a few thousand states (pi_create decides: up to 12 288 in 2-D, 4 096 in 4-D, 1 024 in
 // 6-D) are launch-bound: one sweep is a few microseconds of launch, load -> compute -> gather
@@ -705,6 +782,52 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 #ifndef PI_IMPROVE_REUSE
 #define PI_IMPROVE_REUSE (PI_D >= 4 && PI_NA >= 8)
 #endif
+// The greedy action of one state: argmax_a r(s, a) + gamma E[V](s'), strict '>' from -1.0e30f in ascending
+// action order (reference :262-280).  Shared by the state-order sweeps and the live-list improvement sweep.
+__device__ __forceinline__ void pi_best_action(const float (&x)[PI_D], const float* lds_tab,
+                                               const float* __restrict__ V, float gamma, int& best_out,
+                                               float& best_q_out) {
+    float best_q = -1.0e30f;
+    int best = 0;
+#if PI_IMPROVE_REUSE
+    // Neighbouring actions often land in the same cell (80^4: 41 % of consecutive pairs, 25^6 swing-up
+    // 43 %): the corner values of the cell the lane looked at last stay in registers and only lanes
+    // whose cell changed issue loads — the vector L1 charges per distinct line among the ACTIVE lanes
+    // of each lane quad (profiles/r03/negative_results.txt (16)).
+    PiPair vp[PI_NPAIR];
+#pragma unroll
+    for (int p = 0; p < PI_NPAIR; ++p) vp[p] = PiPair{0.0f, 0.0f};
+    unsigned int held = 0xffffffffu;
+    for (int a = 0; a < PI_NA; ++a) {
+        float ns[PI_D], reward;
+        bool done;
+        pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
+        float e = 0.0f;
+        if (!done) {
+            unsigned int base;
+            float fr[PI_D];
+            pi_locate(ns, base, fr);
+            if (base != held) {
+                pi_request_corners(V, base, vp);
+                held = base;
+            }
+            __builtin_amdgcn_s_setprio(1);
+            e = pi_combine_corners(vp, fr);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        const float q = reward + gamma * e;
+        if (q > best_q) { best_q = q; best = a; }
+    }
+#else
+    for (int a = 0; a < PI_NA; ++a) {
+        const float q = pi_backup(x, lds_tab[PI_TAB_ACT + a], V, gamma);
+        if (q > best_q) { best_q = q; best = a; }
+    }
+#endif
+    best_out = best;
+    best_q_out = best_q;
+}
+
 template <bool WRITE_V>
 __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, float* __restrict__ Vn,
                                                 int* __restrict__ policy,
@@ -742,43 +865,9 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
         if (!cur.term) {
             float x[PI_D];
             pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
-            float best_q = -1.0e30f;
-            int best = 0;
-#if PI_IMPROVE_REUSE
-            // Neighbouring actions often land in the same cell (80^4: 41 % of consecutive pairs, 25^6 swing-up
-            // 43 %): the corner values of the cell the lane looked at last stay in registers and only lanes
-            // whose cell changed issue loads — the vector L1 charges per distinct line among the ACTIVE lanes
-            // of each lane quad (profiles/r03/negative_results.txt (16)).
-            PiPair vp[PI_NPAIR];
-#pragma unroll
-            for (int p = 0; p < PI_NPAIR; ++p) vp[p] = PiPair{0.0f, 0.0f};
-            unsigned int held = 0xffffffffu;
-            for (int a = 0; a < PI_NA; ++a) {
-                float ns[PI_D], reward;
-                bool done;
-                pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
-                float e = 0.0f;
-                if (!done) {
-                    unsigned int base;
-                    float fr[PI_D];
-                    pi_locate(ns, base, fr);
-                    if (base != held) {
-                        pi_request_corners(V, base, vp);
-                        held = base;
-                    }
-                    __builtin_amdgcn_s_setprio(1);
-                    e = pi_combine_corners(vp, fr);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                const float q = reward + gamma * e;
-                if (q > best_q) { best_q = q; best = a; }
-            }
-#else
-            for (int a = 0; a < PI_NA; ++a) {
-                const float q = pi_backup(x, lds_tab[PI_TAB_ACT + a], V, gamma);
-                if (q > best_q) { best_q = q; best = a; }
-            }
-#endif
+            float best_q;
+            int best;
+            pi_best_action(x, lds_tab, V, gamma, best, best_q);
             if (live) {
                 pi_store_lane(policy + sb_c, lane_c, best);
                 n_changed += (cur.action != best) ? 1u : 0u;
@@ -802,6 +891,49 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
                         long long s_begin, long long s_end, float gamma,
                         unsigned int* __restrict__ changed, int cpw) {
     pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed, cpw);
+}
+
+// The improvement sweep over the LIVE states only (the list of pi_prepare_mask; see pi_eval_live_kernel): an
+// improvement sweep never touches terminal states (:253), so every whole-grid launch may take this form.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)
+pi_improve_live_kernel(const float* __restrict__ V, int* __restrict__ policy, const int* __restrict__ live,
+                       const float* __restrict__ tab, long long n_live, float gamma,
+                       unsigned int* __restrict__ changed, int cpw) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(n_live, cpw, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    const unsigned int tid = threadIdx.x;
+    const long long kb0 = chunk0 * PI_BLOCK_IMPROVE;
+    auto lane_of = [&](int k) {
+        return min(tid, (unsigned int)(min(n_live - (kb0 + (long long)k * PI_BLOCK_IMPROVE), (long long)PI_BLOCK_IMPROVE) - 1));
+    };
+    auto entry = [&](int k, unsigned int lane) {
+        return (unsigned int)__builtin_nontemporal_load(pi_lane_ptr(live + kb0 + (long long)k * PI_BLOCK_IMPROVE, lane));
+    };
+    unsigned int lane_cur = lane_of(0);
+    unsigned int s_cur = entry(0, lane_cur);
+    pi_stage_table<PI_BLOCK_IMPROVE>(tab, lds_tab);
+    __syncthreads();
+    unsigned int n_changed = 0;
+    for (int k = 0; k < n_here; ++k) {
+        const unsigned int s = s_cur, lane_c = lane_cur;
+        if (k + 1 < n_here) {
+            lane_cur = lane_of(k + 1);
+            s_cur = entry(k + 1, lane_cur);
+        }
+        const int old_action = __builtin_nontemporal_load(policy + s);    // needed only after the action loop
+        float x[PI_D];
+        pi_state_coords(s, lds_tab, x);
+        float best_q;
+        int best;
+        pi_best_action(x, lds_tab, V, gamma, best, best_q);
+        if (tid == lane_c) {
+            policy[s] = best;
+            n_changed += (old_action != best) ? 1u : 0u;
+        }
+    }
+    if (changed != nullptr) pi_wave_sum_to<PI_BLOCK_IMPROVE>(n_changed, changed);
 }
 
 extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)

@@ -93,6 +93,9 @@ class HipSweepBackend:
         (the kernels then read no mask and, on sweeps without a residual, no old value either)."""
         return 0 if term is None else term.data_ptr()
 
+    def prepare_mask(self, term) -> int:
+        return self.engine.prepare_mask(self._ptr(term), self._stream())
+
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
         self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), self._ptr(term),
                                 s_begin, s_end, gamma, n_sweeps,
@@ -285,6 +288,10 @@ class _CudaPolicyIterationBase(abc.ABC):
         # What the sweeps are given as the mask: the tensor, or None when no grid node is terminal — the
         # kernels then stream neither the mask nor (on sweeps without a residual) the old values.
         self._term_arg = self.d_terminal_mask if (terminal_mask is not None and terminal_mask.any()) else None
+        # the mask is fixed from here on (as in the reference): the library may list the live states once
+        # and visit only those in the later sweeps of an evaluation batch (single rank, big grids)
+        if self._term_arg is not None and self._comm is None and hasattr(self._backend, "prepare_mask"):
+            self._backend.prepare_mask(self._term_arg)
         if self._comm is not None:
             self._comm.plan(self)
             if self._comm.halo_elems >= 0:

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 4
+#define PI_MI355_ABI_VERSION 5
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -109,6 +109,20 @@ int pi_eval_sweep(pi_handle* h, const float* V, float* Vnew, const int32_t* poli
 int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
                    const uint8_t* term, int64_t s_begin, int64_t s_end, float gamma,
                    int n_sweeps, float* d_delta, void* stream);
+
+/*
+ * Optional, once per terminal mask (the reference computes its mask once, at allocation: :150-160): lets the
+ * later sweeps of whole-grid pi_eval_sweeps batches and whole-grid pi_improve_sweep launches (an improvement
+ * sweep never touches terminal states, :253) visit only the NON-terminal states, through a list of
+ * their indices the library builds here (one device-to-host copy of the mask, one upload of the list; blocks
+ * on `stream`).  Worth it where terminal regions cut through many waves — double cartpole 25^6: 35 % of the
+ * states are terminal and 16 % of the waves are partly idle — and skipped where it is not: the list is kept
+ * only when at least 3 % of the grid's lane slots would be idle otherwise and the grid has 2^20 states or more
+ * (pi_info 16 = length of the list in use, 0 = none).  Results are identical with and without it.
+ * Contract: the bytes behind d_term must not change while the list is in use; call again after changing
+ * them, or with d_term == NULL to drop the list.  Batches given another mask pointer ignore the list.
+ */
+int pi_prepare_mask(pi_handle* h, const uint8_t* d_term, void* stream);
 
 /*
  * The whole policy_evaluation loop (:300-336) in ONE launch, for grids the LDS-resident kernel
@@ -289,6 +303,7 @@ int pi_set_option(pi_handle* h, int what, int64_t value);
  * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
  * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
  * batch kernel (0: grid too big for it), 14 that kernel enabled, 15 checked kernels (pi_debug_report),
+ * 16 live states listed by pi_prepare_mask (0: no list in use),
  * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
 

@@ -707,6 +707,141 @@ def test_sharded_value_iteration_and_checkpoint_on_the_native_transport(world, n
         assert (a, b) == (d1, d2)
 
 
+@pytest.mark.parametrize("name,shape", [("cartpole", (11, 9, 13, 8)), ("double_cartpole", (6, 5, 7, 5, 6, 7)),
+                                         ("overhead_crane", (12, 7, 9, 8))])
+def test_live_state_list_changes_speed_not_results(name, shape, cuda_device, monkeypatch):
+    """pi_prepare_mask: later sweeps of a whole-grid batch visit only the non-terminal states through a list.
+    On small grids (the size threshold lowered, graphs and the LDS-resident kernel off so that the eager batch path
+    runs) batches with the list equal batches without it bit for bit in BOTH buffers, with and without a residual;
+    another mask pointer, a sub-range and a single sweep ignore the list; preparing NULL drops it."""
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
+    monkeypatch.setenv("PI_MI355_GRAPHS", "0")
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    cls = envs.ENVS[name]
+    bins, (lo, hi, gshape, strides), states, term, tval = _oracle_grid(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    D, n = len(shape), int(np.prod(shape))
+    assert 0.05 < term.mean() < 0.95
+    eng = _native.Engine(D, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0)
+    eng.compile(envs.dynamics_source(name))
+    rng = np.random.default_rng(17)
+    V0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(cuda_device)
+    pol = torch.from_numpy(rng.integers(0, len(acts), n).astype(np.int32)).to(cuda_device)
+    d_term = torch.from_numpy(term.astype(np.uint8)).to(cuda_device)
+    other = d_term.clone()                                     # same bytes behind another pointer
+    gamma = float(np.float32(0.97))
+
+    def batch(mask, sweeps, residual, s_begin=0, s_end=n):
+        a, b = V0.clone(), torch.full_like(V0, float("nan"))
+        d = torch.full((1,), -1.0, dtype=torch.float32, device=cuda_device)
+        eng.eval_sweeps(a.data_ptr(), b.data_ptr(), pol.data_ptr(), mask.data_ptr(), s_begin, s_end, gamma, sweeps,
+                        d.data_ptr() if residual else 0)
+        torch.cuda.synchronize()
+        return a.cpu().numpy(), b.cpu().numpy(), d.item()
+
+    def improve(mask, s_begin=0, s_end=n):
+        p2 = pol.clone()
+        c = torch.full((1,), 77, dtype=torch.int32, device=cuda_device)
+        eng.improve_sweep(V0.data_ptr(), p2.data_ptr(), mask.data_ptr(), s_begin, s_end, gamma, c.data_ptr())
+        torch.cuda.synchronize()
+        return p2.cpu().numpy(), int(c.item())
+
+    plain = {(k, r): batch(d_term, k, r) for k in (1, 2, 5, 6) for r in (False, True)}
+    part = batch(d_term, 5, True, 7, n - 9)
+    plain_improve, part_improve = improve(d_term), improve(d_term, 7, n - 9)
+    listed = eng.prepare_mask(d_term.data_ptr())
+    pad = np.concatenate([term, np.ones(-n % 64, bool)]).reshape(-1, 64)
+    idle = ((~pad).any(axis=1).sum() * 64 - (~term).sum()) / n          # lane slots idle in partly live waves
+    if idle < 0.03:                                            # the crane: terminal states come in whole planes
+        assert listed == 0 and eng.info(16) == 0
+        eng.close()
+        return
+    assert listed == int((~term).sum()) and eng.info(16) == listed
+    for (k, r), want in plain.items():
+        got = batch(d_term, k, r)
+        for x, y in zip(want[:2], got[:2]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (k, r)
+        assert want[2] == got[2]
+    for got, want in ((improve(d_term), plain_improve), (improve(other), plain_improve),
+                      (improve(d_term, 7, n - 9), part_improve)):
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+    o_pol, o_changed = H.oracle_for(name).improve_sweep(states, acts, pol.cpu().numpy(), V0.cpu().numpy(), term, lo, hi,
+                                                        gshape, strides, gamma)
+    assert np.array_equal(plain_improve[0], o_pol) and plain_improve[1] == o_changed
+    got = batch(other, 5, True)                                # another pointer: list ignored, same result anyway
+    assert np.array_equal(got[1].view(np.uint32), plain[(5, True)][1].view(np.uint32))
+    got = batch(d_term, 5, True, 7, n - 9)                     # sub-range: list ignored
+    assert np.array_equal(got[1].view(np.uint32), part[1].view(np.uint32)) and got[2] == part[2]
+    # and against the oracle: 5 sweeps with the list
+    chk = H.oracle_for(name)
+    cur = V0.cpu().numpy()
+    for _ in range(5):
+        cur, o_delta = chk.eval_sweep(states, acts, pol.cpu().numpy(), cur, term, lo, hi, gshape, strides, gamma)
+    got = batch(d_term, 5, True)
+    H.assert_bits_equal(got[1], cur, "5 sweeps through the live list vs oracle")
+    assert np.float32(got[2]) == np.float32(o_delta)
+    assert eng.prepare_mask(0) == 0 and eng.info(16) == 0
+    eng.close()
+
+
+def test_live_state_list_at_full_c5_size(cuda_device):
+    """The config the list exists for: double cartpole 25^6 (35 % terminal states, 16 % of the waves partly idle).
+    The solver prepares it by itself; three-sweep batches with and without it agree on all 244 M values, and the
+    later sweeps get faster (recorded in profiles/r03, asserted loosely)."""
+    torch = _torch()
+    solver = envs.make("double_cartpole", 25)
+    eng = solver._backend.engine
+    n = solver.n_states
+    assert eng.info(16) == int((solver.d_terminal_mask[:n] == 0).sum().item()) > 0
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    solver.d_value_function[:n].copy_(torch.randn(n, generator=gen, dtype=torch.float32))
+    solver.d_policy[:n].copy_(torch.randint(0, solver.n_actions, (n,), generator=gen, dtype=torch.int32))
+    V0 = solver.d_value_function.clone()
+    term, pol = solver._mask_arg(), solver.d_policy
+    gamma = float(np.float32(solver.config.gamma))
+    d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+
+    def batch(sweeps):
+        a, b = V0.clone(), torch.empty_like(V0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.eval_sweeps(a.data_ptr(), b.data_ptr(), pol.data_ptr(), term.data_ptr(), 0, n, gamma, sweeps, d.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        return a, b, d.item(), e0.elapsed_time(e1)
+
+    def improve():
+        p2 = pol.clone()
+        c = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.improve_sweep(V0.data_ptr(), p2.data_ptr(), term.data_ptr(), 0, n, gamma, c.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        return p2, int(c.item()), e0.elapsed_time(e1)
+
+    with_list = batch(3)
+    t_list = min(batch(11)[3] for _ in range(2))
+    imp_list = improve()
+    ti_list = min(improve()[2] for _ in range(2))
+    eng.prepare_mask(0)
+    without = batch(3)
+    t_plain = min(batch(11)[3] for _ in range(2))
+    imp_plain = improve()
+    ti_plain = min(improve()[2] for _ in range(2))
+    assert torch.equal(imp_list[0], imp_plain[0]) and imp_list[1] == imp_plain[1]
+    print(f"25^6 improvement sweep: {ti_plain:.2f} ms in state order, {ti_list:.2f} ms through the live list")
+    assert ti_list < ti_plain * 1.02
+    assert torch.equal(with_list[0].view(torch.int32), without[0].view(torch.int32))
+    assert torch.equal(with_list[1].view(torch.int32), without[1].view(torch.int32))
+    assert with_list[2] == without[2]
+    print(f"25^6 11-sweep batch: {t_plain:.2f} ms in state order, {t_list:.2f} ms through the live list")
+    assert t_list < t_plain * 1.02
+    solver._backend.close()
+
+
 def _closed_loop(name, bins, start, steps, cuda_device, m=4096):
     """Train `name` on its reference grid with run(), then drive m states in closed loop entirely on the GPU: the
     interpolated action from the batched inference kernel (DevicePolicy on device tensors), the env step from the
