@@ -52,10 +52,15 @@ gather_kernel(const float* __restrict__ buf, float* __restrict__ sink, Stamp* __
     const unsigned int lane = threadIdx.x & 63u;
     // line of this lane within the pattern: neighbouring lanes share a line (grouped), or lanes
     // that share a line sit `lines` apart (interleaved: every quad of lanes spans several lines)
-    const unsigned int group = interleave ? lane % (unsigned int)lines : lane * (unsigned int)lines / 64u;
+    // interleave == 3 ("shifted runs"): grouped, but every run of lanes that share a line starts half a run late, so
+    // that with 16 lines (runs of 4 lanes) every quad of lanes spans TWO lines while the wave still walks 17 runs
+    const unsigned int run = 64u / (unsigned int)lines > 0u ? 64u / (unsigned int)lines : 1u;
+    const unsigned int group = interleave == 3 ? (lane + run / 2u) / run
+                             : interleave ? lane % (unsigned int)lines : lane * (unsigned int)lines / 64u;
     constexpr unsigned int kPerLine = 128u / sizeof(T);                       // elements of T per line
     // with the 4-byte shift the last element of a line would straddle two lines: leave it out
-    const unsigned int in_line = interleave ? lane / (unsigned int)lines : lane % (64u / (unsigned int)lines > 0 ? 64u / (unsigned int)lines : 1u);
+    const unsigned int in_line = interleave == 3 ? (lane + run / 2u) % run
+                               : interleave ? lane / (unsigned int)lines : lane % (64u / (unsigned int)lines > 0 ? 64u / (unsigned int)lines : 1u);
     const unsigned int word = in_line % (kPerLine - (byte_shift ? 1u : 0u));
     // byte offset of this lane inside the pattern: line * 128 + its element
     const unsigned int lane_off = group * 128u + word * (unsigned int)sizeof(T);
@@ -116,6 +121,7 @@ int main(int argc, char** argv) {
     // L1: all workgroups read ONE 128-line (16 KiB) window; L2: one 2 MiB window for everybody.
     const Set sets[] = {{"L1", 128u, 0u, 0}, {"L2", 16384u, 0u, 0}, {"L1+4", 128u, 4u, 0},   // +4: every address = 4 mod 8
                         {"L1i", 128u, 0u, 1}, {"L2i", 16384u, 0u, 1},                        // i: interleaved lanes
+                        {"L1r", 128u, 0u, 3},                                                // r: runs shifted off the quad grid
                         {"same", 1u, 0u, 0}, {"samei", 1u, 0u, 1}};                          // every load re-reads the same lines
     for (const Width& wd : widths)
     for (const Set& set : sets) {
