@@ -33,10 +33,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement), plus
                           ~950 G/s for fp32 fma/mul/add streams AND for mixes with compares / selects /
                           conversions up to 1:1, clustered or not (tools/valu_issue_bench.hip,
                           profiles/r03/valu_issue.txt) — round 2's additive per-class model is withdrawn;
-                    l1    vector-L1 (TCP) tag look-ups/s (TCP_TOTAL_CACHE_ACCESSES) against one look-up per
-                          CU and cycle = 614.4 G/s: a wave-wide 8-byte load costs max(16, lines touched)
-                          look-ups (tools/tcp_gather_bench.hip), so 2^(D-1) corner-pair loads per state put
-                          a floor of 16 x 2^(D-1) look-ups under every wave — 512 per 64 states in 6-D;
+                    l1    the CU's vector-memory path: wave-wide vector loads/s (SQ_INSTS_VMEM_RD) against
+                          CUs x clock / 16 = 38.4 G/s — a wave-wide 8- or 16-byte load occupies the path for
+                          max(16, runs) cycles, a run being up to 4 consecutive lanes in one 128-B line
+                          (tools/tcp_gather_bench.hip, profiles/r03/tcp_gather.txt), so 2^(D-1) corner-pair
+                          loads per state need at least 16 x 2^(D-1) cycles per wave — 512 per 64 states in
+                          6-D; how long the TCP is clocked and how long it waits for L2 fills come with it
+                          (the raw TCP_TOTAL_CACHE_ACCESSES rate too, which is a count, not a utilisation);
                     hbm   HBM-side bytes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) against 8 TB/s.
                   `bound` names the unit with the highest utilisation, `achieved` / `peak` / `frac` are
                   that unit's; `units` carries all three; `traffic` = the HBM-side bytes per launch.
@@ -73,8 +76,14 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0     # wave64 fp32 VALU instructions/s: 2 cycles each per SIMD-32
 VALU_MEASURED_GIPS = 950.0               # what the chip sustains for fp32 and mixed streams (profiles/r03/valu_issue.txt)
-TCP_PEAK_GCYC = 256 * 2.4                # vector-L1 (TCP) tag look-ups per second: one per CU and cycle
-TCP_CYCLES_PER_L2_LINE = 1.23            # extra TCP cycles per TCP->TCC request (profiles/r02/tcp_gather.txt)
+# Vector L1 (TCP / TA).  Every wave-wide 8- or 16-byte load occupies the CU's vector-memory path for at least 16 cycles
+# (4 lanes per cycle) and for max(16, runs) when its lanes fall into more than 16 runs of up to 4 consecutive lanes per
+# 128-B line (profiles/r03/tcp_gather.txt: every pattern measured, none faster).  The unit's roofline is therefore the
+# wave-load rate: achieved = vector load instructions per second (SQ_INSTS_VMEM_RD), peak = CUs x clock / 16.
+# (TCP_TOTAL_CACHE_ACCESSES is NOT a utilisation: it counts (4-lane quad, line) pairs and reaches 2 per cycle on
+# run-structured gathers without the unit being busier; it is reported as accesses_per_cu_cycle for reference.)
+TA_CYCLES_PER_WAVE_LOAD = 16.0
+TCP_PEAK_GLOADS = 256 * 2.4 / TA_CYCLES_PER_WAVE_LOAD          # G wave-wide loads per second
 ENV = "double_pendulum_swingup"
 BINS = 80
 EVAL_PER_STEP = 10
@@ -417,22 +426,24 @@ def main() -> None:
                          "measured_peak": VALU_MEASURED_GIPS, "insts_per_wave": k["valu_insts_per_wave"],
                          "waves_per_launch": waves, "class_split_per_wave": k.get("issue_cycles_model")}
         acc, req = c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), c.get("TCP_TCC_READ_REQ_sum")
-        if acc:
-            ach = acc / sec / 1e9
-            units["l1"] = {"achieved": ach, "peak": TCP_PEAK_GCYC, "unit": "G vector-L1 tag look-ups/s",
-                           "frac": ach / TCP_PEAK_GCYC, "lookups_per_launch": acc, "lookups_per_wave": acc / waves,
-                           "l2_served_lines_per_launch": req, "l1_hit_rate": k.get("l1_hit_rate"),
-                           "pair_loads_floor_lookups_per_64_states": 16 * (1 << (D - 1)),
-                           "with_miss_path": None if req is None else
-                           (acc + TCP_CYCLES_PER_L2_LINE * req) / sec / 1e9 / TCP_PEAK_GCYC,
-                           "note": "with_miss_path adds 1.23 TCP cycles per L2-served line "
-                                   "(profiles/r02/tcp_gather.txt): a model of the unit's busy time, may exceed 1.  "
-                                   "The peak is one look-up per CU and cycle, what saturating microbenchmarks reach "
-                                   "(profiles/r03/tcp_gather.txt); kernels whose lanes change line in runs have "
-                                   "been measured at up to 1.34 on this counter (DESIGN.md section 4), so a "
-                                   "fraction above 1 means 'at the unit's ceiling', not an error"}
-            if units["l1"]["frac"] > 1.0:
-                units["l1"]["exceeds_microbenchmark_ceiling"] = True
+        loads = (k.get("vmem_rd_insts_per_wave") or 0.0) * waves
+        if loads:
+            ach = loads / sec / 1e9
+            tcp = k.get("tcp_per_cu_cycle") or {}
+            units["l1"] = {"achieved": ach, "peak": TCP_PEAK_GLOADS, "unit": "G wave-wide vector loads/s",
+                           "frac": ach / TCP_PEAK_GLOADS, "loads_per_wave": k.get("vmem_rd_insts_per_wave"),
+                           "loads_per_launch": loads,
+                           "accesses_per_launch": acc, "l2_served_lines_per_launch": req,
+                           "accesses_per_cu_cycle": None if not acc else acc / sec / 1e9 / (256 * 2.4),
+                           "l1_hit_rate": k.get("l1_hit_rate"),
+                           "tcp_clocked_frac": tcp.get("TCP_GATE_EN1_sum"),
+                           "tcp_waiting_for_l2_frac": tcp.get("TCP_PENDING_STALL_CYCLES_sum"),
+                           "note": "frac = 16 cycles x vector loads per CU / launch cycles at 2.4 GHz: the share of the "
+                                   "launch the vector-memory path needs at the very least (4 lanes per cycle; loads "
+                                   "whose lanes fall into more than 16 runs need more, 1- and 4-byte loads less).  "
+                                   "tcp_clocked / waiting_for_l2: share of the launch the TCP is clocked / stalled on "
+                                   "L2 fills (same profile).  accesses_per_cu_cycle is the raw counter, not a "
+                                   "utilisation (profiles/r03/tcp_gather.txt)"}
         if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
             traffic = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
             units["hbm"] = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -476,7 +487,7 @@ def main() -> None:
     units = dom.get("units")
     if units:
         name = max(units, key=lambda u: units[u]["frac"])
-        roofline.update({"bound": {"valu": "valu-issue", "l1": "l1-tag-lookups", "hbm": "hbm"}[name],
+        roofline.update({"bound": {"valu": "valu-issue", "l1": "l1-load-issue", "hbm": "hbm"}[name],
                          "achieved": units[name]["achieved"], "peak": units[name]["peak"],
                          "unit": units[name]["unit"], "frac": units[name]["frac"], "units": units,
                          "clock_GHz_under_profiler": dom.get("clock_GHz_under_profiler")})
