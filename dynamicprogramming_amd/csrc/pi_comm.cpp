@@ -671,6 +671,17 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
     hipStream_t st = (hipStream_t)stream;
     pi::ShardPlan* p = h->plan;
     const bool overlap = p->halo && p->comm_stream != nullptr;
+    // One launch range of one sweep: the later sweeps of a batch (k >= 1) visit only the range's live states when
+    // the handle holds a list for this mask (pi_prepare_mask) — the first one copies the terminal values.
+    const bool live = pi::live_usable(h, term);
+    auto sweep = [&](const float* src, float* dst, int64_t a, int64_t b, bool want, int k) -> int {
+        if (k >= 1 && live) {
+            int64_t first = 0, count = 0;
+            pi::live_span(h, a, b, &first, &count);
+            return pi::launch_eval_live(h, src, dst, policy, first, count, gamma, want, st);
+        }
+        return pi::launch_eval(h, src, dst, policy, term, a, b, gamma, want, st, k >= 1);
+    };
     auto batch = [&]() -> int {
         for (int k = 0; k < n_sweeps; ++k) {
             const float* src = (k & 1) ? Vb : Va;
@@ -678,16 +689,16 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
             const bool want = k == n_sweeps - 1 && d_delta != nullptr;
             if (overlap) {
                 for (const auto& r : p->send_ranges)
-                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st, k >= 1)) return 1;
+                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 PI_HIP(hipEventRecord(p->ev_ready, st));
                 PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
                 if (post_exchange(h, dst, p->comm_stream)) return 1;
                 PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
                 for (const auto& r : p->interior)
-                    if (pi::launch_eval(h, src, dst, policy, term, r.first, r.second, gamma, want, st, k >= 1)) return 1;
+                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
             } else {
-                if (pi::launch_eval(h, src, dst, policy, term, p->s_begin, p->s_end, gamma, want, st, k >= 1)) return 1;
+                if (sweep(src, dst, p->s_begin, p->s_end, want, k)) return 1;
                 if (pi_exchange_V(h, dst, stream)) return 1;
             }
         }

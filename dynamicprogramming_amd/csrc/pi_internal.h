@@ -88,6 +88,8 @@ struct pi_handle {
     const uint8_t* live_term = nullptr;
     int32_t* d_live = nullptr;
     int64_t live_count = 0;
+    std::vector<uint64_t> live_bits;     // host: bit s of word s / 64 = state s is live (30 MB for 25^6)
+    std::vector<int64_t> live_before;    // host: live states before each 64-state block -> list position of any state
     pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank
     pi::ShardPlan* plan = nullptr;       // exchange plan (owned; pi_comm.cpp)
 };
@@ -105,6 +107,13 @@ int launch_eval(pi_handle* h, const float* V, float* Vnew, const int32_t* policy
                 int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st,
                 bool keep_terminals = false);
 int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
+// The live-state list of pi_prepare_mask.  live_usable: a list is in use and `term` is the mask it was built from.
+// live_span: the run of list entries whose states lie in [s_begin, s_end).  launch_eval_live: one evaluation sweep
+// over `count` list entries from position `first` — for sweeps that need not copy terminal values.
+bool live_usable(const pi_handle* h, const uint8_t* term);
+void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
+int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
+                     float gamma, bool want_delta, hipStream_t st);
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
 // hipRTC (gfx950, -O3 -ffp-contract=off) or the on-disk code-object cache -> image of one translation unit
 int compile_image(const std::string& src, const char* cache_dir, char* log, size_t log_len,

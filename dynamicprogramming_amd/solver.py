@@ -289,8 +289,10 @@ class _CudaPolicyIterationBase(abc.ABC):
         # kernels then stream neither the mask nor (on sweeps without a residual) the old values.
         self._term_arg = self.d_terminal_mask if (terminal_mask is not None and terminal_mask.any()) else None
         # the mask is fixed from here on (as in the reference): the library may list the live states once
-        # and visit only those in the later sweeps of an evaluation batch (single rank, big grids)
-        if self._term_arg is not None and self._comm is None and hasattr(self._backend, "prepare_mask"):
+        # and visit only those in the later sweeps of an evaluation batch and in the improvement sweeps
+        # (big grids whose terminal regions cut through many waves; every rank lists the whole grid and
+        # sweeps the part of the list that lies in its launch ranges)
+        if self._term_arg is not None and hasattr(self._backend, "prepare_mask"):
             self._backend.prepare_mask(self._term_arg)
         if self._comm is not None:
             self._comm.plan(self)

@@ -713,7 +713,8 @@ def test_live_state_list_changes_speed_not_results(name, shape, cuda_device, mon
     """pi_prepare_mask: later sweeps of a whole-grid batch visit only the non-terminal states through a list.
     On small grids (the size threshold lowered, graphs and the LDS-resident kernel off so that the eager batch path
     runs) batches with the list equal batches without it bit for bit in BOTH buffers, with and without a residual;
-    another mask pointer, a sub-range and a single sweep ignore the list; preparing NULL drops it."""
+    sub-ranges use the part of the list that lies in them; another mask pointer and a single sweep ignore the
+    list; preparing NULL drops it."""
     torch = _torch()
     monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
     monkeypatch.setenv("PI_MI355_GRAPHS", "0")
@@ -772,7 +773,7 @@ def test_live_state_list_changes_speed_not_results(name, shape, cuda_device, mon
     assert np.array_equal(plain_improve[0], o_pol) and plain_improve[1] == o_changed
     got = batch(other, 5, True)                                # another pointer: list ignored, same result anyway
     assert np.array_equal(got[1].view(np.uint32), plain[(5, True)][1].view(np.uint32))
-    got = batch(d_term, 5, True, 7, n - 9)                     # sub-range: list ignored
+    got = batch(d_term, 5, True, 7, n - 9)                     # sub-range: the entries of the list inside it
     assert np.array_equal(got[1].view(np.uint32), part[1].view(np.uint32)) and got[2] == part[2]
     # and against the oracle: 5 sweeps with the list
     chk = H.oracle_for(name)
@@ -784,6 +785,55 @@ def test_live_state_list_changes_speed_not_results(name, shape, cuda_device, mon
     assert np.float32(got[2]) == np.float32(o_delta)
     assert eng.prepare_mask(0) == 0 and eng.info(16) == 0
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["halo", "allgather"])
+@pytest.mark.parametrize("world,name,shape", [(2, "cartpole", (10, 8, 11, 7)), (4, "double_cartpole", (8, 4, 5, 4, 5, 4))])
+def test_live_state_list_in_the_sharded_driver(world, name, shape, mode, cuda_device, monkeypatch):
+    """Every rank of a sharded run sweeps the part of the live-state list that lies in its launch ranges (swept-first
+    and interior ranges alike): `world` logical ranks through the in-process transport, the size threshold lowered
+    so that these small grids get a list — run() bit-identical to the single-rank run without a list."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 3, "max_eval_iter": 60}
+    monkeypatch.setenv("PI_MI355_LIVE", "0")
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
+    assert single._backend.engine.info(16) == 0
+    single.run()
+    monkeypatch.setenv("PI_MI355_LIVE", "1")
+    monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
+    monkeypatch.setenv("PI_MI355_GRAPHS", "0")
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    monkeypatch.setenv("PI_MI355_EXCHANGE", mode)
+    group = f"live-{uuid.uuid4().hex}"
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            stream = torch.cuda.Stream(device=cuda_device)
+            with torch.cuda.stream(stream):
+                s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device,
+                        transport=T.NativeTransport.local(r, world, group))
+                listed = s._backend.engine.info(16)
+                s.run()
+            out[r] = (s.value_function, s.policy, list(s.stats["sweeps_per_iter"]), listed)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(world):
+        V, pol, sweeps, listed = out[r]
+        assert listed > 0
+        H.assert_bits_equal(V, single.value_function, f"rank {r} V")
+        assert np.array_equal(pol, single.policy) and sweeps == single.stats["sweeps_per_iter"]
 
 
 def test_live_state_list_at_full_c5_size(cuda_device):

@@ -108,6 +108,7 @@ for o in out:
     eng = s._backend.engine
     st = torch.cuda.current_stream(dev).cuda_stream
     parts = {0: 0.0, 1: 0.0}
+    later = {0: 0.0, 1: 0.0}
     for kind in (0, 1):
         rs = [(a, b) for k, a, b in o["ranges"] if k == kind]
         if not rs:
@@ -121,7 +122,21 @@ for o in out:
             e1.record()
             e1.synchronize()
         parts[kind] = e0.elapsed_time(e1) / 5
+        # the LATER sweeps of a batch (no terminal copies; over the live-state list where the handle holds one):
+        # (a 9-sweep batch - a 1-sweep batch) / 8 per range
+        def batches(k):
+            e0.record()
+            for a, b in rs:
+                eng.eval_sweeps(s.d_value_function.data_ptr(), s.d_new_value_function.data_ptr(), s.d_policy.data_ptr(),
+                                s.d_terminal_mask.data_ptr(), a, b, gamma, k, 0, st)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        batches(2)
+        later[kind] = (min(batches(9) for _ in range(2)) - min(batches(1) for _ in range(2))) / 8.0
     o["first_ms"], o["interior_ms"] = parts[0], parts[1]
+    o["first_later_sweeps_ms"], o["interior_later_sweeps_ms"] = later[0], later[1]
+    o["live_states_listed"] = eng.info(16)
     o["first_launches"] = sum(1 for k, _, _ in o["ranges"] if k == 0)
     o["interior_launches"] = sum(1 for k, _, _ in o["ranges"] if k == 1)
     o["first_states"] = sum(b - a for k, a, b in o["ranges"] if k == 0)
