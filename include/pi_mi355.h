@@ -112,15 +112,17 @@ int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
 
 /*
  * Optional, once per terminal mask (the reference computes its mask once, at allocation: :150-160): lets the
- * later sweeps of whole-grid pi_eval_sweeps batches and whole-grid pi_improve_sweep launches (an improvement
- * sweep never touches terminal states, :253) visit only the NON-terminal states, through a list of
+ * later sweeps of pi_eval_sweeps / pi_eval_sweeps_sharded batches and pi_improve_sweep(_sharded) launches (an
+ * improvement sweep never touches terminal states, :253) visit only the NON-terminal states of their range — for the
+ * sharded driver: of every launch range of the rank — through a list of
  * their indices the library builds here (one device-to-host copy of the mask, one upload of the list; blocks
  * on `stream`).  Worth it where terminal regions cut through many waves — double cartpole 25^6: 35 % of the
  * states are terminal and 16 % of the waves are partly idle — and skipped where it is not: the list is kept
  * only when at least 3 % of the grid's lane slots would be idle otherwise and the grid has 2^20 states or more
  * (pi_info 16 = length of the list in use, 0 = none).  Results are identical with and without it.
  * Contract: the bytes behind d_term must not change while the list is in use; call again after changing
- * them, or with d_term == NULL to drop the list.  Batches given another mask pointer ignore the list.
+ * them, or with d_term == NULL to drop the list.  Calls given another mask pointer ignore the list.  The list
+ * covers the whole grid on every rank (4 B per live state on the device, n / 8 + n / 8 bytes of index on the host).
  */
 int pi_prepare_mask(pi_handle* h, const uint8_t* d_term, void* stream);
 
