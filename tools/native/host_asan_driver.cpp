@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
         CHECK(pi_eval_sweep(h, &dummy, &dummy, nullptr, nullptr, 0, 1, 0.9f, nullptr, nullptr) != 0);   // host-only: refuses
         uint32_t rep[4];
         CHECK(pi_debug_report(h, rep) != 0);
+        CHECK(pi_prepare_mask(h, nullptr, nullptr) != 0);                     // host-only handle: refused
         pi_destroy(h);
     }
     // exchange planner (host-only): random reach bitmaps, every world size, tiny caps
