@@ -74,9 +74,11 @@ SIGNATURES = {
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
     "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "pi_prepare_mask": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_eval_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "pi_eval_end": (ctypes.c_int, [_vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 _load_error: Exception | None = None
 
@@ -216,6 +218,15 @@ class Engine:
         (0 drops the list); returns the number of live states listed, 0 when the library keeps none."""
         _check(lib().pi_prepare_mask(self._h, term or None, stream or None), "pi_prepare_mask")
         return self.info(16)
+
+    def eval_begin(self, policy, term, stream=0) -> int:
+        """Start of one policy evaluation under the policy at `policy`: returns the length of the shorter list the
+        following whole-grid batches may use (0: none).  Pair with eval_end()."""
+        _check(lib().pi_eval_begin(self._h, policy, term or None, stream or None), "pi_eval_begin")
+        return self.info(17)
+
+    def eval_end(self) -> None:
+        _check(lib().pi_eval_end(self._h), "pi_eval_end")
 
     def debug_report(self) -> dict:
         """Checked build only (PI_MI355_DEBUG=1 when the engine was created): index violations of the sweeps

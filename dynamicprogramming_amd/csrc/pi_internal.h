@@ -67,7 +67,7 @@ struct pi_handle {
     float* d_tab = nullptr;
     unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed
     hipModule_t module = nullptr;
-    hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
+    hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr, f_resident = nullptr;
     int num_cu = 0;
@@ -88,6 +88,14 @@ struct pi_handle {
     const uint8_t* live_term = nullptr;
     int32_t* d_live = nullptr;
     int64_t live_count = 0;
+    // pi_eval_begin .. pi_eval_end: the live states that bootstrap under the policy at eval_policy (device list,
+    // capacity live_count); eval_count < 0: none.  eval_holds: buffers every live state of which has been written
+    // by a full sweep since pi_eval_begin — a sweep may use the shorter list only between two such buffers.
+    int32_t* d_eval_list = nullptr;
+    unsigned long long* d_eval_cursor = nullptr;     // per-block survivor counts -> offsets (+ total)
+    int64_t eval_count = -1;
+    const int32_t* eval_policy = nullptr;
+    std::vector<const float*> eval_holds;
     std::vector<uint64_t> live_bits;     // host: bit s of word s / 64 = state s is live (30 MB for 25^6)
     std::vector<int64_t> live_before;    // host: live states before each 64-state block -> list position of any state
     pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank
@@ -113,7 +121,8 @@ int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
 bool live_usable(const pi_handle* h, const uint8_t* term);
 void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
 int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
-                     float gamma, bool want_delta, hipStream_t st);
+                     float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);
+void drop_eval_list(pi_handle* h);     // the policy may have changed: forget the per-evaluation list
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
 // hipRTC (gfx950, -O3 -ffp-contract=off) or the on-disk code-object cache -> image of one translation unit
 int compile_image(const std::string& src, const char* cache_dir, char* log, size_t log_len,

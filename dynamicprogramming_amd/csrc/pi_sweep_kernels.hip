@@ -606,6 +606,77 @@ pi_eval_live_kernel(const float* __restrict__ V, float* __restrict__ Vn, const i
     if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
 }
 
+// ---- per-evaluation list: live states whose successor is not terminal ----------------------
+// Under a FIXED policy a live state whose successor (s, pi(s)) is terminal has V'(s) = reward + gamma * 0 in every
+// sweep of the evaluation, whatever V is: once both Jacobi buffers hold that value (after the evaluation's first two
+// sweeps) the state need not be visited again until the policy changes — its residual contribution is 0.  This
+// kernel filters the live list down to the states that DO bootstrap (double cartpole 25^6: ~85-90 % of the live
+// ones), keeping the ascending order the sweeps' XCD-aware chunk schedule relies on (an unordered append — blocks in
+// completion order — made the sweeps 30 % SLOWER): pass 0 counts the survivors of every 256-entry block, a scan
+// turns the counts into offsets, pass 1 repeats the test and writes the survivors at their block's offset.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_policy_list_kernel(const int* __restrict__ live, long long n_live, const int* __restrict__ policy,
+                      const float* __restrict__ tab, unsigned long long* __restrict__ block_slots,
+                      int* __restrict__ out, int pass) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ unsigned int wave_count[PI_BLOCK / 64];
+    pi_stage_table<PI_BLOCK>(tab, lds_tab);
+    __syncthreads();
+    const long long k = (long long)blockIdx.x * PI_BLOCK + threadIdx.x;
+    bool keep = false;
+    int s = 0;
+    if (k < n_live) {
+        s = live[k];
+        float x[PI_D], ns[PI_D], reward;
+        pi_state_coords((unsigned int)s, lds_tab, x);
+        bool done;
+        pi_dynamics(x, lds_tab[PI_TAB_ACT + pi_checked_action(policy[s], (unsigned int)s)], ns, &reward, &done);
+        keep = !done;
+    }
+    const unsigned long long votes = __ballot(keep);
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wave] = (unsigned int)__popcll(votes);
+    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x == 0) {
+            unsigned int total = 0;
+            for (int w = 0; w < PI_BLOCK / 64; ++w) total += wave_count[w];
+            block_slots[blockIdx.x] = total;
+        }
+    } else if (keep) {
+        unsigned int before = 0;
+        for (unsigned int w = 0; w < wave; ++w) before += wave_count[w];
+        before += (unsigned int)__popcll(votes & ((1ull << lane) - 1ull));
+        out[block_slots[blockIdx.x] + before] = s;
+    }
+}
+// In-place exclusive scan of `count` block counts (one workgroup of 1 024 threads walks them 1 024 at a time with a
+// running carry); slots[count] receives the total.
+extern "C" __global__ void __launch_bounds__(1024)
+pi_scan_slots_kernel(unsigned long long* __restrict__ slots, long long count) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (long long base = 0; base < count; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const unsigned long long mine = i < count ? slots[i] : 0ull;
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (unsigned int step = 1; step < 1024u; step <<= 1) {              // inclusive Hillis-Steele scan
+            const unsigned long long add = threadIdx.x >= step ? part[threadIdx.x - step] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < count) slots[i] = carry + part[threadIdx.x] - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slots[count] = carry;
+}
+
 // ---- LDS-resident evaluation batch for small grids ----------------------------------------
 // Grids of a few thousand states (pi_create decides: up to 12 288 in 2-D, 4 096 in 4-D, 1 024 in
 // 6-D) are launch-bound: one sweep is a few microseconds of launch, load -> compute -> gather

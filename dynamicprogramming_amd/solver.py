@@ -96,6 +96,12 @@ class HipSweepBackend:
     def prepare_mask(self, term) -> int:
         return self.engine.prepare_mask(self._ptr(term), self._stream())
 
+    def eval_begin(self, policy, term) -> int:
+        return self.engine.eval_begin(policy.data_ptr(), self._ptr(term), self._stream())
+
+    def eval_end(self) -> None:
+        self.engine.eval_end()
+
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta):
         self.engine.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), policy.data_ptr(), self._ptr(term),
                                 s_begin, s_end, gamma, n_sweeps,
@@ -376,21 +382,30 @@ class _CudaPolicyIterationBase(abc.ABC):
             return self._policy_evaluation_resident(gamma, t0)
         i = 0
         sweeps = 0
-        while i < cfg.max_eval_iter:
-            check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
-            check = min(check, cfg.max_eval_iter - 1)
-            n = check - i + 1
-            self._evaluation_sweeps(n, gamma)
-            sweeps += n
-            i = check + 1
-            delta = float(self._d_delta.item())          # the one host sync per 25 sweeps
-            if check % cfg.log_interval == 0:
-                logger.debug(f"  Eval iter {check:5d} | delta = {delta:.4e}")
-            if delta < cfg.theta:
-                logger.success(f"  Eval converged at iter {check} | delta = {delta:.2e}")
-                break
-        else:
-            logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+        # the policy is fixed for the whole loop: the library may drop the states whose successor is terminal
+        # from the later sweeps (single rank, grids with a live-state list; same results)
+        bracket = self._comm is None and hasattr(self._backend, "eval_begin")
+        if bracket:
+            self._backend.eval_begin(self.d_policy, self._mask_arg())
+        try:
+            while i < cfg.max_eval_iter:
+                check = i if i % SYNC_INTERVAL == 0 else (i // SYNC_INTERVAL + 1) * SYNC_INTERVAL
+                check = min(check, cfg.max_eval_iter - 1)
+                n = check - i + 1
+                self._evaluation_sweeps(n, gamma)
+                sweeps += n
+                i = check + 1
+                delta = float(self._d_delta.item())          # the one host sync per 25 sweeps
+                if check % cfg.log_interval == 0:
+                    logger.debug(f"  Eval iter {check:5d} | delta = {delta:.4e}")
+                if delta < cfg.theta:
+                    logger.success(f"  Eval converged at iter {check} | delta = {delta:.2e}")
+                    break
+            else:
+                logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+        finally:
+            if bracket:
+                self._backend.eval_end()
         self.stats["eval_sweeps"] += sweeps
         self.stats["sweeps_per_iter"].append(sweeps)
         self.stats["eval_seconds"] += time.perf_counter() - t0

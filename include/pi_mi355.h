@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 5
+#define PI_MI355_ABI_VERSION 6
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -125,6 +125,21 @@ int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
  * covers the whole grid on every rank (4 B per live state on the device, n / 8 + n / 8 bytes of index on the host).
  */
 int pi_prepare_mask(pi_handle* h, const uint8_t* d_term, void* stream);
+
+/*
+ * Optional bracket around one policy_evaluation (:300-336), for handles with a live-state list: under a FIXED
+ * policy a live state whose successor is terminal has V'(s) = reward + gamma * 0 in every sweep, so once both
+ * Jacobi buffers hold that value it need not be visited again.  pi_eval_begin filters the live list down to the
+ * states that bootstrap under `policy` (one launch, one 8-byte read-back; blocks on `stream`; the shorter list is
+ * kept when it saves at least 3 %), and until pi_eval_end whole-grid pi_eval_sweeps batches with this policy
+ * pointer use it for every sweep whose source AND destination buffer have been written by a full sweep since
+ * pi_eval_begin (the library tracks the buffers; with the reference's ping-pong that is every sweep after the
+ * evaluation's second).  Results are identical with and without the bracket.  pi_info 17 = entries in use.
+ * Contract: between begin and end neither the policy array nor the value buffers are written by anyone but
+ * the evaluation sweeps; pi_improve_sweep / pi_value_sweep end the bracket by themselves.
+ */
+int pi_eval_begin(pi_handle* h, const int32_t* policy, const uint8_t* term, void* stream);
+int pi_eval_end(pi_handle* h);
 
 /*
  * The whole policy_evaluation loop (:300-336) in ONE launch, for grids the LDS-resident kernel
@@ -305,7 +320,8 @@ int pi_set_option(pi_handle* h, int what, int64_t value);
  * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
  * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
  * batch kernel (0: grid too big for it), 14 that kernel enabled, 15 checked kernels (pi_debug_report),
- * 16 live states listed by pi_prepare_mask (0: no list in use),
+ * 16 live states listed by pi_prepare_mask (0: no list in use), 17 entries of the per-evaluation list of
+ * pi_eval_begin (0: none),
  * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
 

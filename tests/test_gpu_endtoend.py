@@ -836,6 +836,75 @@ def test_live_state_list_in_the_sharded_driver(world, name, shape, mode, cuda_de
         assert np.array_equal(pol, single.policy) and sweeps == single.stats["sweeps_per_iter"]
 
 
+@pytest.mark.parametrize("name,shape", [("cartpole", (11, 9, 13, 8)), ("double_cartpole", (6, 5, 7, 5, 6, 7))])
+def test_per_evaluation_list_changes_speed_not_results(name, shape, cuda_device, monkeypatch):
+    """pi_eval_begin / pi_eval_end: under a fixed policy the live states whose successor is terminal drop out of the
+    sweeps once both buffers hold their (constant) value.  Engine level: the same sequences of batches — the solver's
+    1 + 25 + 25 pattern, a caller that never swaps its buffers, single-sweep batches — give the same bits in both
+    buffers and the same residuals with and without the bracket; an improvement sweep ends the bracket.  Solver level:
+    a full run() equals the run without the bracket (V, policy, sweeps of every evaluation)."""
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
+    monkeypatch.setenv("PI_MI355_GRAPHS", "0")
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    cls = envs.ENVS[name]
+    bins, (lo, hi, gshape, strides), states, term, tval = _oracle_grid(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    D, n = len(shape), int(np.prod(shape))
+    eng = _native.Engine(D, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0)
+    eng.compile(envs.dynamics_source(name))
+    rng = np.random.default_rng(23)
+    V0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(cuda_device)
+    pol = torch.from_numpy(rng.integers(0, len(acts), n).astype(np.int32)).to(cuda_device)
+    d_term = torch.from_numpy(term.astype(np.uint8)).to(cuda_device)
+    gamma = float(np.float32(0.97))
+    assert eng.prepare_mask(d_term.data_ptr()) > 0
+
+    def sequence(pattern, bracket):
+        a, b = V0.clone(), torch.full_like(V0, float("nan"))
+        d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+        deltas, listed = [], 0
+        if bracket:
+            listed = eng.eval_begin(pol.data_ptr(), d_term.data_ptr())
+        for k, swap in pattern:
+            eng.eval_sweeps(a.data_ptr(), b.data_ptr(), pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, k, d.data_ptr())
+            torch.cuda.synchronize()
+            deltas.append(d.item())
+            if swap and k % 2:
+                a, b = b, a
+        if bracket:
+            eng.eval_end()
+        return a.cpu().numpy(), b.cpu().numpy(), deltas, listed
+
+    live = int((~term).sum())
+    for pattern in ([(1, True), (25, True), (25, True)],            # the solver's loop
+                    [(3, False), (4, False), (5, False)],           # a caller that never swaps
+                    [(1, True)] * 6,                                # single-sweep batches
+                    [(2, True), (7, True)]):
+        want = sequence(pattern, False)
+        got = sequence(pattern, True)
+        assert 0 < got[3] < live, got[3]
+        for x, y in zip(want[:2], got[:2]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), pattern
+        assert want[2] == got[2], pattern
+    # an improvement sweep ends the bracket by itself (the policy may have changed)
+    assert eng.eval_begin(pol.data_ptr(), d_term.data_ptr()) > 0 and eng.info(17) > 0
+    eng.improve_sweep(V0.data_ptr(), pol.clone().data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
+    assert eng.info(17) == 0
+    eng.close()
+    # solver level
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PI_MI355_EVAL_LIST", flag)
+        s = cls(H.env_bins_space(name, shape), cls.ACTIONS,
+                envs.CudaPIConfig(**{**cls.CONFIG, "max_pi_iter": 4, "max_eval_iter": 120}), device=cuda_device)
+        s.run()
+        runs[flag] = (s.value_function, s.policy, list(s.stats["sweeps_per_iter"]))
+    H.assert_bits_equal(runs["1"][0], runs["0"][0], "run() with the per-evaluation list")
+    assert np.array_equal(runs["1"][1], runs["0"][1]) and runs["1"][2] == runs["0"][2]
+
+
 def test_live_state_list_at_full_c5_size(cuda_device):
     """The config the list exists for: double cartpole 25^6 (35 % terminal states, 16 % of the waves partly idle).
     The solver prepares it by itself; three-sweep batches with and without it agree on all 244 M values, and the
