@@ -80,6 +80,8 @@ int main(int argc, char** argv) {
         uint32_t rep[4];
         CHECK(pi_debug_report(h, rep) != 0);
         CHECK(pi_prepare_mask(h, nullptr, nullptr) != 0);                     // host-only handle: refused
+        int32_t one_policy[1] = {0};
+        CHECK(pi_eval_begin(h, one_policy, nullptr, nullptr) != 0 && pi_eval_end(h) == 0 && pi_eval_end(nullptr) != 0);
         pi_destroy(h);
     }
     // exchange planner (host-only): random reach bitmaps, every world size, tiny caps
