@@ -70,6 +70,28 @@ def test_dynamics_bit_exact(name, cuda_device):
     eng.close()
 
 
+@pytest.mark.parametrize("name", list(H.STEP_PYTHON_ENVS))
+def test_dynamics_match_reference_step_python(name, cuda_device):
+    """step_dynamics on the GPU against vectors the reference's OWN `_step_python` produced (reference-executed
+    code, tests/golden/make_step_python_golden.py): next state within 1e-5 relative (angles on the circle), reward
+    within 5e-5 relative, `terminated` exact wherever the successor is 1e-4 or more from every threshold."""
+    torch = _torch()
+    g = np.load(H.GOLDEN / "step_python.npz")
+    st, act = g[f"{name}_states"], g[f"{name}_actions"]
+    D, m = st.shape[1], len(st)
+    eng, _, _ = _engine(name, H.golden(name)["g0_shape"], cuda_device)
+    d_st, d_act = _dev(st, cuda_device), _dev(act, cuda_device)
+    d_next = torch.empty((m, D), dtype=torch.float32, device=cuda_device)
+    d_rew = torch.empty(m, dtype=torch.float32, device=cuda_device)
+    d_done = torch.empty(m, dtype=torch.uint8, device=cuda_device)
+    eng.probe_step(d_st.data_ptr(), d_act.data_ptr(), d_next.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), m)
+    torch.cuda.synchronize()
+    got = H.check_against_step_python(name, d_next.cpu().numpy(), d_rew.cpu().numpy(),
+                                      d_done.cpu().numpy().astype(bool), "GPU")
+    assert got["flags_compared"] >= m - 10
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["pendulum", "double_pendulum_swingup", "double_cartpole"])
 @pytest.mark.parametrize("gi", [0, 1])
 def test_interpolation_matches_reference_golden(name, gi, cuda_device):
