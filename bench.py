@@ -18,7 +18,20 @@ run.  Either the caller starts the ranks (`python -m torch.distributed.run --npr
 bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or plain
 `python bench.py --gpus N` does: it then starts exactly that command as a CHILD process (before
 anything touches the GPU; never an exec), relays rank 0's JSON line and exits with the child's
-code.  `--launch-dry-run` prints the child command instead of running it.
+code.  `--launch-dry-run` prints the child command and the fallback ladder instead of running them.
+
+N > 1 cannot be rehearsed before the driver's scaling run (one GPU per development box), so a rank
+started by the launcher does not touch the GPU itself: it SUPERVISES.  Every rank's supervisor joins a
+gloo (CPU) group over the launcher's rendezvous and starts the real rank as a fresh child process
+(`PI_BENCH_WORKER=1`, its own rendezvous port agreed over gloo), once per rung of a fallback ladder —
+halo exchange overlapped with the interior sweep (the library's default) -> halo exchange without overlap
+-> all-gather — each rung with a time limit (`--attempt-timeout`, 240 s).  The supervisors agree twice a
+second on "some rank failed / every rank is done / time is up" (a three-word all-reduce); a failed or
+late rung is killed everywhere (process groups) and the next one starts in new processes — a process that
+has touched the GPU is never re-executed.  Rank 0 relays the first successful line with
+`check.exchange.attempts` = what happened on every rung.  Inside the ranks, before the timed region, two
+sharded evaluation sweeps and one sharded improvement sweep are compared bit for bit with the unsharded
+sweeps of the same state (`check.exchange.bit_identical`); a mismatch fails the rung.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
   roofline      — dominant kernel of the step (pi_eval_sweep_kernel in every BASELINE config; pi_eval_live_kernel,
@@ -105,7 +118,8 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict:
-    """Oracle timed on host cores over every k-th state of the same grid / V / policy."""
+    """Oracle timed on host cores over every k-th state of the same grid / V / policy: on every core of this
+    process's affinity mask (`value`, `cores`), on 16 threads (a one-GPU box's share) and on one thread."""
     import oracle
     from dynamicprogramming_amd import envs
     cls = envs.ENVS[env]
@@ -116,7 +130,11 @@ def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict
     V = rng.standard_normal(n).astype(np.float32)
     chk = oracle.build(cls._D, envs.dynamics_source(env))
     gamma = np.float32(cls.CONFIG["gamma"])
-    all_threads = chk.threads
+    checker_threads = chk.threads
+    try:
+        all_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        all_cores = os.cpu_count() or 1
 
     def run(m, threads):
         stride = max(n // m, 1)
@@ -137,16 +155,19 @@ def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict
         return len(flat) * (EVAL_PER_STEP + IMPROVE_PER_STEP * len(cls.ACTIONS)) / dt, dt, stride
 
     m_all = min(sample_states, n)
-    many, dt_many, stride_many = run(m_all, all_threads)
+    many, dt_many, stride_many = run(m_all, all_cores)
+    mid_threads = min(16, all_cores)
+    mid, dt_mid, stride_mid = (many, dt_many, stride_many) if mid_threads == all_cores else run(max(m_all // 2, 1), mid_threads)
     one, dt_one, stride_one = run(max(m_all // 16, 1), 1)
-    chk.set_threads(all_threads)
-    return {"value": many, "unit": "backups/s", "cores": all_threads, "kind": "port",
+    chk.set_threads(checker_threads)
+    return {"value": many, "unit": "backups/s", "cores": all_cores, "kind": "port",
+            "value_16_threads": mid, "threads_16": mid_threads,
             "value_1_thread": one, "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
             "numpy_reference_c1": numpy_reference_c1(),
             "sample": f"one step (10 eval + 1 improve sweeps) over every {stride_many}-th state of the same "
-                      f"{bins}^{cls._D} grid ({m_all} states, {dt_many:.1f} s wall, "
-                      f"oracle/pi_oracle.cpp with OpenMP, {all_threads} threads); 1 thread: every "
-                      f"{stride_one}-th state, {dt_one:.1f} s wall"}
+                      f"{bins}^{cls._D} grid ({m_all} states, {dt_many:.1f} s wall, oracle/pi_oracle.cpp with OpenMP on "
+                      f"all {all_cores} threads of the affinity mask); {mid_threads} threads: every {stride_mid}-th state, "
+                      f"{dt_mid:.1f} s; 1 thread: every {stride_one}-th state, {dt_one:.1f} s"}
 
 
 def numpy_reference_c1() -> dict:
@@ -199,25 +220,154 @@ def launch_command(n_gpus: int, argv: list[str], port: int | None = None) -> lis
             "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + rest
 
 
-def self_launch(n_gpus: int, argv: list[str], dry_run: bool) -> int:
-    """Start the ranks as a child process (never exec: nothing here has touched the GPU, and nothing
-    will), pass their stderr through, relay rank 0's one JSON line, return the child's exit code
-    (non-zero when any rank failed or no line was printed)."""
-    cmd = launch_command(n_gpus, argv)
-    if dry_run:
-        print(json.dumps({"launch": cmd, "note": "dry run: the ranks were not started"}), flush=True)
-        return 0
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+# Fallback ladder of an N-rank run: (name, environment of the ranks).  The library reads PI_MI355_EXCHANGE /
+# PI_MI355_OVERLAP when the exchange is planned (dynamicprogramming_amd/transport.py, csrc/pi_comm.cpp).
+LADDER = [
+    ("halo+overlap", {}),                                         # library default: halo unless it is > 60 % of an all-gather
+    ("halo", {"PI_MI355_OVERLAP": "0"}),                          # whole shard, then the exchange on the same stream
+    ("allgather", {"PI_MI355_EXCHANGE": "allgather", "PI_MI355_OVERLAP": "0"}),   # one ncclAllGather per sweep
+]
+ATTEMPT_TIMEOUT = 240.0
+
+
+def _free_port() -> int:
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def worker_command(argv: list[str]) -> list[str]:
+    """What a supervisor starts as the real rank (a fresh process per rung of the ladder)."""
+    return [sys.executable, str(Path(__file__).resolve())] + [a for a in argv if a != "--launch-dry-run"]
+
+
+def kill_process_group(proc: subprocess.Popen, grace: float = 5.0) -> None:
+    """End a child started with start_new_session=True together with everything it started."""
+    import signal
+    if proc.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, grace)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait)
+            return
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def result_line(text: str):
+    """The last stdout line that is a bench result (a JSON object with "metric"), or None."""
     line = None
-    for cand in proc.stdout.splitlines():
+    for cand in text.splitlines():
         try:
             obj = json.loads(cand)
         except ValueError:
             continue
         if isinstance(obj, dict) and "metric" in obj:
             line = cand
+    return line
+
+
+def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=None) -> int:
+    """One rank of an N-rank run as started by the launcher: never touches the GPU.  Runs the real rank as a child
+    process, rung by rung of the fallback ladder, in lockstep with the other ranks' supervisors (gloo)."""
+    import datetime
+    import threading
+    import torch
+    import torch.distributed as dist
+    ladder = LADDER if ladder is None else ladder
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=attempt_timeout * len(ladder) + 300))
+    attempts, line = [], None
+    try:
+        for k, (mode, extra) in enumerate(ladder):
+            port = [_free_port() if rank == 0 else None]          # the ranks' own rendezvous: a fresh port per rung
+            dist.broadcast_object_list(port, src=0)
+            env = {**os.environ, **extra, "PI_BENCH_WORKER": "1", "PI_BENCH_ATTEMPT": str(k), "PI_BENCH_MODE": mode,
+                   "MASTER_PORT": str(port[0])}
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            proc = subprocess.Popen(worker_command(argv), env=env, text=True, start_new_session=True,
+                                    stdout=subprocess.PIPE if rank == 0 else sys.stderr)
+            chunks: list[str] = []
+            reader = None
+            if rank == 0:
+                reader = threading.Thread(target=lambda: chunks.append(proc.stdout.read()), daemon=True)
+                reader.start()
+            t0 = time.monotonic()
+            while True:
+                rc = proc.poll()
+                flags = torch.tensor([int(rc not in (None, 0)), int(rc == 0), int(time.monotonic() - t0 > attempt_timeout)],
+                                     dtype=torch.int32)
+                dist.all_reduce(flags)                            # the same verdict on every rank, twice a second
+                failed, done, late = (int(v) for v in flags.tolist())
+                if failed or late or done == world:
+                    break
+                time.sleep(0.5)
+            ok = done == world and not failed
+            if not ok:
+                kill_process_group(proc)
+            if reader is not None:
+                reader.join(timeout=10.0)
+            codes = [None] * world
+            dist.all_gather_object(codes, proc.poll() if (ok or rc is not None) else None)
+            got = result_line("".join(chunks)) if rank == 0 else None
+            verdict = [bool(ok and (rank != 0 or got is not None))]
+            dist.broadcast_object_list(verdict, src=0)            # rank 0 also needs the line
+            attempts.append({"mode": mode, "ok": verdict[0], "seconds": round(time.monotonic() - t0, 1),
+                             "exit_codes": codes, "timeout": bool(late and not failed and not ok)})
+            if rank == 0:
+                print(f"bench.py: rung {k} ({mode}): {'ok' if verdict[0] else 'failed'} "
+                      f"{json.dumps(attempts[-1])}", file=sys.stderr, flush=True)
+            if verdict[0]:
+                line = got
+                break
+        if rank == 0 and line is not None:
+            obj = json.loads(line)
+            obj.setdefault("check", {})
+            if not isinstance(obj["check"].get("exchange"), dict):
+                obj["check"]["exchange"] = {}
+            obj["check"]["exchange"]["attempts"] = attempts
+            print(json.dumps(obj), flush=True)
+        success = bool(attempts and attempts[-1]["ok"])
+        if rank == 0 and not success:
+            print(f"bench.py: every rung of the ladder failed: {json.dumps(attempts)}", file=sys.stderr, flush=True)
+        return 0 if success else 1
+    finally:
+        dist.destroy_process_group()
+
+
+def self_launch(n_gpus: int, argv: list[str], dry_run: bool, attempt_timeout: float = ATTEMPT_TIMEOUT) -> int:
+    """Start the ranks as a child process (never exec: nothing here has touched the GPU, and nothing
+    will), pass their stderr through, relay rank 0's one JSON line, return the child's exit code
+    (non-zero when any rank failed or no line was printed).  The child is bounded in time (the whole
+    ladder plus start-up) and killed with its process group when it overruns."""
+    cmd = launch_command(n_gpus, argv)
+    if dry_run:
+        print(json.dumps({"launch": cmd, "worker": worker_command(argv),
+                          "ladder": [{"mode": m, "env": e, "timeout_s": attempt_timeout} for m, e in LADDER],
+                          "note": "dry run: the ranks were not started.  Every rank started by the launch line supervises: "
+                                  "it runs `worker` as a fresh child per rung until one rung succeeds on all ranks"}),
+              flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it
+    limit = attempt_timeout * len(LADDER) + 300.0
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        kill_process_group(proc)
+        stdout = ""
+        try:
+            stdout, _ = proc.communicate(timeout=10.0)
+        except subprocess.TimeoutExpired:
+            pass
+        print(f"bench.py: the {n_gpus}-rank child overran {limit:.0f} s and was killed", file=sys.stderr)
+        return 124
+    line = result_line(stdout or "")
     if line is not None:
         print(line, flush=True)
     if proc.returncode != 0:
@@ -227,6 +377,38 @@ def self_launch(n_gpus: int, argv: list[str], dry_run: bool) -> int:
         print("bench.py: the ranks printed no result line", file=sys.stderr)
         return 1
     return 0
+
+
+def sharded_equals_unsharded(solver, eng, gamma, torch, dist) -> dict:
+    """Two evaluation sweeps (the second one reads what the first one's exchange delivered) and one improvement sweep
+    through the sharded driver, then the same three sweeps over the whole grid on this rank alone (every rank holds a
+    full-size V), compared with torch.equal on every rank.  Restores the solver's V / policy afterwards."""
+    n = solver.n_states
+    V0, P0 = solver.d_value_function.clone(), solver.d_policy.clone()
+    term = solver._backend._ptr(solver._mask_arg())
+    stream = torch.cuda.current_stream().cuda_stream
+    solver._evaluation_sweeps(2, gamma)
+    solver._improvement_sweep(gamma)
+    solver._comm.all_gather(solver, solver.d_value_function)
+    solver._comm.all_gather(solver, solver.d_policy)
+    residual, changed = float(solver._d_delta.item()), int(solver._d_changed.item())
+    A, B, P = V0.clone(), V0.clone(), P0.clone()
+    d_delta = torch.zeros(1, dtype=torch.float32, device=V0.device)
+    d_changed = torch.zeros(1, dtype=torch.int32, device=V0.device)
+    eng.eval_sweep(A.data_ptr(), B.data_ptr(), P.data_ptr(), term, 0, n, gamma, 0, stream)
+    eng.eval_sweep(B.data_ptr(), A.data_ptr(), P.data_ptr(), term, 0, n, gamma, d_delta.data_ptr(), stream)
+    eng.improve_sweep(A.data_ptr(), P.data_ptr(), term, 0, n, gamma, d_changed.data_ptr(), stream)
+    torch.cuda.synchronize()
+    same = [bool(torch.equal(A[:n], solver.d_value_function[:n])), bool(torch.equal(P[:n], solver.d_policy[:n])),
+            float(d_delta.item()) == residual, int(d_changed.item()) == changed]
+    verdict = torch.tensor([int(all(same))], dtype=torch.int32, device=V0.device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    solver.d_value_function.copy_(V0)
+    solver.d_new_value_function.copy_(V0)
+    solver.d_policy.copy_(P0)
+    torch.cuda.synchronize()
+    return {"ok": bool(verdict.item()), "V": same[0], "policy": same[1], "residual": same[2], "changed": same[3],
+            "sweeps": "2 evaluation + 1 improvement, sharded vs whole grid on one rank, torch.equal on every rank"}
 
 
 def main() -> None:
@@ -254,14 +436,21 @@ def main() -> None:
                          "the 1-thread run takes every 16th of those)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="with --gpus N > 1 outside torch.distributed.run: print the child command that "
-                         "would start the N ranks, and exit")
+                         "would start the N ranks and the fallback ladder, and exit")
+    ap.add_argument("--attempt-timeout", type=float, default=ATTEMPT_TIMEOUT,
+                    help="N > 1: seconds one rung of the fallback ladder may take before it is killed on every rank")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # started by torch.distributed.run
     if not launched and (args.gpus > 1 or args.launch_dry_run):
-        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_dry_run))
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_dry_run, args.attempt_timeout))
+    if launched and int(os.environ["WORLD_SIZE"]) > 1 and os.environ.get("PI_BENCH_WORKER") != "1":
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's "
+                             f"--nproc-per-node must equal --gpus")
+        sys.exit(supervise(sys.argv[1:], args.attempt_timeout))
 
     import torch
     import torch.distributed as dist
@@ -294,6 +483,19 @@ def main() -> None:
     solver.d_new_value_function.copy_(solver.d_value_function)
     solver.d_policy[:n].copy_(P0)
     del V0, P0
+    n_live = n - int(solver.d_terminal_mask[:n].sum().item())     # non-terminal states: the ones a sweep backs up
+
+    # ── N > 1: sharded sweeps against the unsharded sweeps of the same state, bit for bit, before anything is timed ──
+    bit_identical = None
+    if world > 1:
+        bit_identical = sharded_equals_unsharded(solver, eng, gamma, torch, dist)
+        if not bit_identical["ok"]:
+            if rank == 0:
+                print(f"bench.py: sharded sweeps differ from the unsharded ones: {json.dumps(bit_identical)}",
+                      file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            sys.exit(3)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -350,7 +552,11 @@ def main() -> None:
         live_ms = (min(batch_ms(21) for _ in range(2)) - first_ms) / 20.0
     backups_per_step = n * (EVAL_PER_STEP + IMPROVE_PER_STEP * nA)
     value = backups_per_step * args.steps / elapsed
+    # terminal states are COUNTED in `value` ("count terminal states too if simpler, but say which"); they do
+    # no work, so the figure over the states a sweep really backs up stands beside it
+    value_nonterminal = n_live * (EVAL_PER_STEP + IMPROVE_PER_STEP * nA) * args.steps / elapsed
     states_per_launch = solver._s_end - solver._s_begin
+    live_per_launch = (states_per_launch - int(solver.d_terminal_mask[solver._s_begin:solver._s_end].sum().item()))
 
     # ── the evaluation sweep on a policy-iteration state (what a real run() sweeps) ──────────
     converged = None
@@ -400,16 +606,25 @@ def main() -> None:
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
-    prof, prof_path = load_profile(args.env, args.bins, n, khash) if world == 1 else (None, None)
+    prof, prof_path = load_profile(args.env, args.bins, n, khash)
+    # N > 1: the committed profile is the single-GPU launch of the same kernel; per-wave figures carry over, the number
+    # of waves (and every per-launch total) scales with this rank's share of the states
+    prof_scale = states_per_launch / float(n)
     bytes_eval = algorithmic_bytes_eval(D)
     bytes_improve = 4 * (1 << D) + (4 * D + 1 + 4) / nA
-    compulsory = 13.0 * states_per_launch       # V read + V' write + policy + mask, cache-perfect
+    # cache-perfect HBM bytes of one evaluation sweep: every V value read once (4) + V' written (4) + the policy entry (4),
+    # + the mask byte on grids that have terminal states (the old-value stream is read on residual sweeps only, 1 in 25)
+    compulsory_per_state = 12.0 if solver._mask_arg() is None else 13.0
+    compulsory = compulsory_per_state * states_per_launch
 
     def kernel_entry(name, ms, backups, alg_bytes_per_backup, counters=None):
         """Timing of one kernel plus, when a matching profile exists, the utilisation of the three
         units it can be bound by (VALU issue, vector-L1 tag look-ups, HBM)."""
         sec = ms * 1e-3
         e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups, "backups_per_s": backups / sec}
+        if n_live != n:
+            e["backups_per_launch_live"] = int(round(backups * live_per_launch / float(states_per_launch)))
+            e["backups_per_s_live"] = e["backups_per_launch_live"] / sec
         alg = alg_bytes_per_backup * backups / sec / 1e9
         e["algorithmic"] = {"bytes_per_backup": alg_bytes_per_backup, "achieved_GBps": alg,
                             "note": "SURVEY 8(d) byte model; served by L1/L2/Infinity Cache, not a bound"}
@@ -417,7 +632,7 @@ def main() -> None:
         if not k or "valu_insts_per_wave" not in k:
             return e
         c = k["counters"]
-        waves = c["SQ_WAVES"]
+        waves = c["SQ_WAVES"] * prof_scale
         units = {}
         insts = k["valu_insts_per_wave"] * waves
         ach = insts / sec / 1e9
@@ -426,6 +641,7 @@ def main() -> None:
                          "measured_peak": VALU_MEASURED_GIPS, "insts_per_wave": k["valu_insts_per_wave"],
                          "waves_per_launch": waves, "class_split_per_wave": k.get("issue_cycles_model")}
         acc, req = c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), c.get("TCP_TCC_READ_REQ_sum")
+        acc, req = (None if acc is None else acc * prof_scale), (None if req is None else req * prof_scale)
         loads = (k.get("vmem_rd_insts_per_wave") or 0.0) * waves
         if loads:
             ach = loads / sec / 1e9
@@ -445,7 +661,7 @@ def main() -> None:
                                    "L2 fills (same profile).  accesses_per_cu_cycle is the raw counter, not a "
                                    "utilisation (profiles/r03/tcp_gather.txt)"}
         if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
-            traffic = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
+            traffic = (2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]) * prof_scale
             units["hbm"] = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": traffic / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
                             "l2_hit_rate": k.get("l2_hit_rate")}
@@ -482,6 +698,11 @@ def main() -> None:
     roofline = {"bound": None, "kernel": dom["kernel"], "achieved": None, "peak": None, "unit": None, "frac": None,
                 "traffic": None, "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash,
                 "profile": prof_path,
+                "profile_scaled_to_rank_share": None if world == 1 else prof_scale,
+                "compulsory_bytes_per_state": compulsory_per_state,
+                "vmem_rd_note": "vector loads per wave of two chunks = 16 corner-pair loads + 2 policy loads + 7/16 (the "
+                                "table-staging load is exec-masked: 411 table floats, so 7 of a workgroup's 16 waves issue "
+                                "it) + 2 old-value loads on the 1 sweep in 25..50 that reports a residual",
                 "peak_source": "MI355X_MICROARCH.md: VALU 1228.8 G wave64 instr/s (2 cycles x 1024 SIMDs x 2.4 GHz); "
                                "vector L1 one tag look-up per CU and cycle = 614.4 G/s; HBM3E 8 TB/s"}
     units = dom.get("units")
@@ -518,11 +739,14 @@ def main() -> None:
                                 "bytes_received_per_sweep": (table[:, 2] * 4).astype(np.int64).tolist(),
                                 "bytes_sent_per_sweep": (table[:, 3] * 4).astype(np.int64).tolist(),
                                 "states": table[:, 4].astype(np.int64).tolist()}
+        exchange["bit_identical"] = bit_identical
+        exchange["ladder_mode"] = os.environ.get("PI_BENCH_MODE")
         exchange["eval_ms_max"], exchange["eval_ms_min"] = float(table[:, 0].max()), float(table[:, 0].min())
         exchange["bytes_received_per_sweep_max"] = int(table[:, 2].max() * 4)
     out = {
         "metric": "state-action Bellman backups/sec",
         "value": value,
+        "value_nonterminal": value_nonterminal,
         "unit": "backups/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -535,8 +759,9 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"{args.env} {D}D grid bins={args.bins}/dim "
                                f"({n} states) x {nA} actions, gamma={solver.config.gamma}; step = {EVAL_PER_STEP} "
-                               f"eval sweeps + {IMPROVE_PER_STEP} improve sweep = {backups_per_step} backups",
-                   "states": n, "actions": nA, "eval_sweeps_per_step": EVAL_PER_STEP,
+                               f"eval sweeps + {IMPROVE_PER_STEP} improve sweep = {backups_per_step} backups; terminal "
+                               f"states are counted in `value` ({n - n_live} of {n}: value_nonterminal leaves them out)",
+                   "states": n, "nonterminal_states": n_live, "actions": nA, "eval_sweeps_per_step": EVAL_PER_STEP,
                    "improve_sweeps_per_step": IMPROVE_PER_STEP,
                    "parallelism": f"state-range shards x{world}" + (
                        f", {exchange['mode']} exchange of V' per eval sweep over RCCL inside libpi_mi355"
@@ -555,7 +780,7 @@ def main() -> None:
                   "interpolation_reciprocal_division": [eng.info(20 + d) for d in range(D)],
                   "exchange": exchange},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:            # rank 0's host cores; the other ranks wait at the barrier below
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -57,3 +57,119 @@ def test_child_line_is_relayed_and_failures_propagate(monkeypatch, capsys):
 
     monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, "-c", noise])
     assert bench.self_launch(2, ["--gpus", "2"], dry_run=False) == 1             # no result line -> failure
+
+
+# ── the ranks' supervisors (N > 1): fallback ladder, time limit, lockstep over gloo — with fake ranks ──────────────
+FAKE_RANK = r'''
+import json, os, sys, time
+rank, attempt, mode = int(os.environ["RANK"]), int(os.environ["PI_BENCH_ATTEMPT"]), os.environ["PI_BENCH_MODE"]
+assert os.environ["PI_BENCH_WORKER"] == "1"
+plan = json.loads(os.environ["FAKE_PLAN"])            # per attempt: what each rank does
+what = plan[attempt][rank] if attempt < len(plan) else "ok"
+if mode == "halo":
+    assert os.environ.get("PI_MI355_OVERLAP") == "0"
+if mode == "allgather":
+    assert os.environ.get("PI_MI355_EXCHANGE") == "allgather"
+if what == "hang":
+    time.sleep(600)
+if what.startswith("exit"):
+    sys.exit(int(what[4:]))
+if rank == 0:
+    print("noise before")
+    print(json.dumps({"metric": "m", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"]),
+                      "check": {"exchange": {"mode": mode, "port": os.environ["MASTER_PORT"]}}}))
+'''
+
+
+def _supervisor_rank(rank, world, port, plan, timeout, queue):
+    import contextlib
+    import io
+    import os
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FAKE_PLAN": json.dumps(plan)})
+    bench = _bench()
+    bench.worker_command = lambda argv: [sys.executable, "-c", FAKE_RANK]
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        rc = bench.supervise(["--gpus", str(world)], attempt_timeout=timeout)
+    queue.put((rank, rc, out.getvalue()))
+
+
+def _run_supervisors(plan, timeout=30.0, world=2):
+    import multiprocessing as mp
+    bench = _bench()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = bench._free_port()
+    procs = [ctx.Process(target=_supervisor_rank, args=(r, world, port, plan, timeout, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(queue.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return got
+
+
+def test_supervisors_relay_the_first_rung_when_it_works():
+    (r0, rc0, out0), (r1, rc1, out1) = _run_supervisors([["ok", "ok"]])
+    assert (rc0, rc1) == (0, 0) and out1.strip() == ""
+    (line,) = out0.strip().splitlines()                                  # exactly one line, on rank 0
+    obj = json.loads(line)
+    assert obj["check"]["exchange"]["mode"] == "halo+overlap"
+    assert [a["ok"] for a in obj["check"]["exchange"]["attempts"]] == [True]
+
+
+def test_a_failing_rank_moves_every_rank_to_the_next_rung():
+    # rung 0: rank 1 exits 3 while rank 0 would hang in a collective; rung 1 (halo, no overlap) works
+    got = _run_supervisors([["hang", "exit3"], ["ok", "ok"]], timeout=60.0)
+    (_, rc0, out0), (_, rc1, _) = got
+    assert (rc0, rc1) == (0, 0)
+    obj = json.loads(out0.strip().splitlines()[-1])
+    att = obj["check"]["exchange"]["attempts"]
+    assert [a["mode"] for a in att] == ["halo+overlap", "halo"] and [a["ok"] for a in att] == [False, True]
+    assert att[0]["exit_codes"][1] == 3 and att[0]["timeout"] is False
+    assert att[0]["seconds"] < 30                                        # the hung rank was killed at once, not at the limit
+    assert obj["check"]["exchange"]["mode"] == "halo"
+
+
+def test_a_hung_rung_is_killed_at_the_time_limit_and_the_ladder_ends_in_allgather():
+    got = _run_supervisors([["hang", "hang"], ["exit1", "ok"], ["ok", "ok"]], timeout=4.0)
+    (_, rc0, out0), (_, rc1, _) = got
+    assert (rc0, rc1) == (0, 0)
+    att = json.loads(out0.strip().splitlines()[-1])["check"]["exchange"]["attempts"]
+    assert [a["mode"] for a in att] == ["halo+overlap", "halo", "allgather"]
+    assert att[0]["timeout"] is True and att[1]["ok"] is False and att[2]["ok"] is True
+    # every rung had its own rendezvous port
+
+
+def test_when_every_rung_fails_every_rank_fails():
+    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"]], timeout=30.0)
+    assert [rc for _, rc, _ in got] == [1, 1]
+    assert all(out.strip() == "" for _, _, out in got)                  # no result line is invented
+
+
+def test_dry_run_shows_the_ladder():
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--launch-dry-run"], capture_output=True,
+                         text=True, timeout=120, env={k: v for k, v in __import__("os").environ.items()
+                                                      if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert res.returncode == 0, res.stderr
+    obj = json.loads(res.stdout.strip().splitlines()[-1])
+    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap", "halo", "allgather"]
+    assert obj["ladder"][2]["env"]["PI_MI355_EXCHANGE"] == "allgather" and obj["ladder"][0]["timeout_s"] == 240.0
+    assert obj["worker"][1].endswith("bench.py")
+
+
+def test_self_launch_kills_a_child_that_overruns(monkeypatch):
+    bench = _bench()
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, "-c", "import time; time.sleep(600)"])
+    monkeypatch.setattr(bench, "LADDER", [])                            # limit = 0 x timeout + 300 -> patch the constant part too
+    import time as _t
+    t0 = _t.monotonic()
+    real_popen = subprocess.Popen
+
+    class Quick(real_popen):
+        def communicate(self, input=None, timeout=None):                # noqa: A002
+            return super().communicate(input=input, timeout=min(timeout or 2.0, 2.0))
+    monkeypatch.setattr(bench.subprocess, "Popen", Quick)
+    assert bench.self_launch(2, ["--gpus", "2"], dry_run=False) == 124
+    assert _t.monotonic() - t0 < 60

@@ -21,6 +21,7 @@ usage: python tools/phase_timeline.py [--env E] [--bins B] [--out profiles/r04/p
 """
 import argparse
 import ctypes
+import os
 import re
 import json
 import subprocess
@@ -39,6 +40,34 @@ PT_KERNELS = r'''
 // ---- diagnostic copies of pi_eval_sweep_kernel (tools/phase_timeline.py) ----
 #ifndef PT_TRACE
 #define PT_TRACE 0
+#endif
+#ifndef PT_REORDER
+#define PT_REORDER 0
+#endif
+#ifndef PT_PF_DIST
+#define PT_PF_DIST 0
+#endif
+#ifndef PT_AFFINE
+#define PT_AFFINE 0
+#endif
+#if PT_AFFINE
+// Grid coordinates without the LDS copy of the bin tables: x_d = (float)((double)i_d * step_d + start_d), two float64
+// operations and one conversion, verified on the host to reproduce EVERY float32 entry of the table (the tables are
+// np.linspace outputs, i.e. float64 affine sequences rounded to float32).  The action value of a lane comes out of a
+// register that holds the action table across the lanes of the wave (ds_bpermute: the LDS crossbar, no LDS memory).
+// Nothing is staged, so the workgroup needs no barrier and a wave's first dependence on memory is its policy entry.
+constexpr double PT_AFF_A[PI_D] = PT_AFF_A_INIT;
+constexpr double PT_AFF_B[PI_D] = PT_AFF_B_INIT;
+__device__ __forceinline__ void pt_state_coords(unsigned int s, float (&x)[PI_D]) {
+    unsigned int r = s;
+#pragma unroll
+    for (int d = PI_D - 1; d > 0; --d) {
+        unsigned int q = r / (unsigned int)PI_GRID.g[d];
+        x[d] = (float)((double)(r - q * (unsigned int)PI_GRID.g[d]) * PT_AFF_B[d] + PT_AFF_A[d]);
+        r = q;
+    }
+    x[0] = (float)((double)r * PT_AFF_B[0] + PT_AFF_A[0]);
+}
 #endif
 #define PT_WORDS 64
 #if PT_TRACE
@@ -66,7 +95,13 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
                      unsigned int trace_cap, int it0) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     int tr = 0;
+    PiStateIn nxt_init;
+    nxt_init.v_old = 0.0f; nxt_init.action = 0; nxt_init.term = 0;
     PT_STAMP(2);
+#if PT_TRACE
+    PT_WAIT_ALL();                                      // the kernel arguments (s_load from the kernarg segment) are in
+    PT_STAMP(21);
+#endif
     const unsigned int tid = threadIdx.x;
     long long c, c_end, c_step;
     if (PERSISTENT) {
@@ -86,9 +121,53 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
     }
     long long sb = s_begin + c * PI_BLOCK_EVAL;
     unsigned int lane = min(tid, (unsigned int)(min(s_end - sb, (long long)PI_BLOCK_EVAL) - 1));
+#if PT_AFFINE
+    static_assert(PI_NA <= 64, "action table across the lanes of one wave");
+    PiStateIn nxt = pi_load_state(V, policy, nullptr, sb, lane, false);
+    float act_lanes = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PI_NA; ++j) act_lanes = ((tid & 63u) == (unsigned int)j) ? tab[PI_TAB_ACT + j] : act_lanes;
+#elif PT_REORDER
+    // table loads first, then the policy stream: vmcnt counts in order, so the LDS stores and the workgroup's barrier
+    // wait for L2-served table lines only while the first policy load (an HBM miss) is still in flight
+    {
+        constexpr int kPer = (PI_GRID.tab_len + PI_BLOCK_EVAL - 1) / PI_BLOCK_EVAL;
+        float t[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) t[j] = tab[min(j * PI_BLOCK_EVAL + (int)tid, PI_GRID.tab_len - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        PiStateIn first = pi_load_state(V, policy, nullptr, sb, lane, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = j * PI_BLOCK_EVAL + (int)tid;
+            if (i < PI_GRID.tab_len) lds_tab[i] = t[j];
+        }
+        __syncthreads();
+        nxt_init = first;
+    }
+    PiStateIn nxt = nxt_init;
+#else
     PiStateIn nxt = pi_load_state(V, policy, nullptr, sb, lane, false);
     pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
     __syncthreads();
+#endif
+#if PT_PF_DIST > 0
+    // touch the first chunk's policy lines of the workgroup that will take over this CU's slots half a lifetime or so
+    // later (PT_PF_DIST groups ahead on this XCD), so that ITS prologue finds them in L2 instead of HBM
+    int pf_word = 0;
+    if (!PERSISTENT) {
+        const long long n_chunks_all = (s_end - s_begin + PI_BLOCK_EVAL - 1) / PI_BLOCK_EVAL;
+        const long long groups = (n_chunks_all + cpw - 1) / cpw;
+        const long long span = (groups + PI_NXCD - 1) / PI_NXCD;
+        const long long j = blockIdx.x / PI_NXCD, g2 = (blockIdx.x % PI_NXCD) * span + j + PT_PF_DIST;
+        if (j + PT_PF_DIST < span && g2 < groups) {
+            const long long sb2 = s_begin + g2 * cpw * PI_BLOCK_EVAL;
+            const unsigned int lane2 = min(tid, (unsigned int)(min(s_end - sb2, (long long)PI_BLOCK_EVAL) - 1));
+            pf_word = *pi_lane_ptr(policy + sb2, lane2);
+        }
+    }
+#endif
     PT_STAMP(3);
     int it = 0;
     for (; c < c_end; c += c_step, ++it) {
@@ -107,8 +186,13 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
         if (rec) PT_STAMP2(0);                    // A: chunk begins, next chunk's inputs requested
 #endif
         float x[PI_D], ns[PI_D], reward;
+#if PT_AFFINE
+        pt_state_coords((unsigned int)sb_c + lane_c, x);
+        const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(cur.action << 2, __float_as_int(act_lanes)));
+#else
         pi_state_coords((unsigned int)sb_c + lane_c, lds_tab, x);
         const float a = lds_tab[PI_TAB_ACT + cur.action];
+#endif
 #if PT_TRACE
         if (rec) { if (more) PT_WAIT_BUT1(); else PT_WAIT_ALL(); PT_STAMP2(1); }   // B: this chunk's inputs are in registers
 #endif
@@ -142,6 +226,9 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
         if (rec) PT_STAMP2(5);                    // F: weights + fmaf chain + store issued
 #endif
     }
+#if PT_PF_DIST > 0
+    if (pf_word == 0x7fffffff) Vn[0] = 0.0f;          // keeps the touch alive; policy entries are action indices
+#endif
 #if PT_TRACE
     PT_STAMP(16);
     const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
@@ -152,7 +239,7 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
         PT_PUT(blockIdx.x, 17);
         PT_PUT(__builtin_amdgcn_readfirstlane(tid >> 6), 18);
         PT_PUT(it, 19);
-        PT_PUT((unsigned int)__builtin_amdgcn_s_memrealtime(), 20);
+        PT_PUT((unsigned int)__builtin_amdgcn_s_memrealtime(), 22);
         unsigned int slot0 = 0u;
         if ((tid & 63u) == 0u) slot0 = atomicAdd(trace_count, 1u);
         slot0 = __builtin_amdgcn_readfirstlane(slot0);
@@ -179,16 +266,19 @@ PHASES = ["A>B wait for inputs", "B>C dynamics + cell search", "C>D issue corner
           "E>F weights + fmaf chain + store"]
 
 
-def build(src_text: str, trace: int, block: int, tmp: Path, tag: str):
+EXTRA_FLAGS: list = []
+
+
+def build(src_text: str, trace: int, block: int, tmp: Path, tag: str, defines: str = ""):
     tag_f = re.sub(r"[^A-Za-z0-9_]+", "_", tag)
     src = tmp / f"pt_{tag_f}.hip"
     text, hits = re.subn(r"#define PI_BLOCK_EVAL \d+", f"#define PI_BLOCK_EVAL {block}", src_text, count=1)
     assert hits == 1
-    src.write_text(f"#define PT_TRACE {trace}\n" + text + PT_KERNELS)
+    src.write_text(f"#define PT_TRACE {trace}\n" + defines + text + PT_KERNELS)
 
     out = tmp / f"pt_{tag_f}.hsaco"
     res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "--genco",
-                          "-include", "hip/hip_runtime.h", "-Rpass-analysis=kernel-resource-usage", str(src), "-o", str(out)],
+                          "-include", "hip/hip_runtime.h", "-Rpass-analysis=kernel-resource-usage", *EXTRA_FLAGS, str(src), "-o", str(out)],
                          capture_output=True, text=True)
     if res.returncode != 0:
         raise SystemExit(res.stderr[-4000:])
@@ -202,6 +292,43 @@ def build(src_text: str, trace: int, block: int, tmp: Path, tag: str):
                 if key in line:
                     usage[fn][key.strip(" :")] = line.split(":")[-1].strip()
     return out, {k: v for k, v in usage.items() if k.startswith("pt_") or k == "pi_eval_sweep_kernel"}
+
+
+def affine_fit(table: np.ndarray, max_exceptions: int = 2):
+    """(a, b, exceptions) with float32(i * b + a) == table[i] (float64 multiply, float64 add, one conversion — what the
+    kernel does) for every i outside `exceptions` = [(i, table[i])...], or None.  np.linspace tables are float64 affine
+    sequences rounded to float32; their entries next to zero (the middle of a symmetric odd grid is a rounding residue
+    like 4e-16) cannot be hit by any affine real function, hence the exceptions.  The admissible (a, b) form a convex
+    polygon — one strip per entry: the reals that round to table[i] — whose a-width is concave in b: ternary search."""
+    t = np.asarray(table, np.float32)
+    g = len(t)
+    t64 = t.astype(np.float64)
+    up = np.nextafter(t, np.float32(np.inf)).astype(np.float64)
+    dn = np.nextafter(t, np.float32(-np.inf)).astype(np.float64)
+    hi, lo = t64 + 0.5 * (up - t64), t64 - 0.5 * (t64 - dn)
+    i = np.arange(g, dtype=np.float64)
+    use = np.abs(t64) > 1e-4 * np.abs(t64).max()
+    if use.sum() < 2:
+        return None
+    iu, hu, lu = i[use], hi[use], lo[use]
+    width = lambda b: (hu - iu * b).min() - (lu - iu * b).max()   # noqa: E731
+    span = iu[-1] - iu[0]
+    b_lo, b_hi = (lu[-1] - hu[0]) / span, (hu[-1] - lu[0]) / span
+    for _ in range(200):
+        m1, m2 = b_lo + (b_hi - b_lo) / 3.0, b_hi - (b_hi - b_lo) / 3.0
+        if width(m1) < width(m2):
+            b_lo = m1
+        else:
+            b_hi = m2
+    b = 0.5 * (b_lo + b_hi)
+    if width(b) <= 0.0:
+        return None
+    a = 0.5 * ((hu - iu * b).min() + (lu - iu * b).max())
+    got = (i * b + a).astype(np.float32)              # float64 multiply, float64 add, one rounding to float32
+    bad = np.flatnonzero(got.view(np.uint32) != t.view(np.uint32))
+    if len(bad) > max_exceptions:
+        return None
+    return float(a), float(b), [(int(k), float(t[k])) for k in bad]
 
 
 class Module:
@@ -253,6 +380,7 @@ def fold(rec: np.ndarray, lines: list, label: str):
                  f"({len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist())))} CUs), chunks per wave {np.median(its):.0f}")
     lines.append(f"wave lifetime (entry -> end), shader cycles: median {np.median(life):.0f}  p10 {np.percentile(life, 10):.0f}  "
                  f"p90 {np.percentile(life, 90):.0f}")
+    lines.append(f"entry -> kernel arguments loaded: median {np.median(d(2, 21)):.0f}  p90 {np.percentile(d(2, 21), 90):.0f}")
     lines.append(f"entry -> tables staged + barrier passed: median {np.median(d(2, 3)):.0f}  p90 {np.percentile(d(2, 3), 90):.0f}")
     tot = np.zeros(len(rec))
     for k in range(2):
@@ -329,8 +457,13 @@ def main():
     ap.add_argument("--compile-only", action="store_true", help="build every variant without a GPU and print its registers")
     ap.add_argument("--blocks", default="", help="extra (threads, cpw) pairs for the copy, e.g. 512x2,512x4,1024x4")
     ap.add_argument("--state", choices=["bench", "zero"], default="bench")
+    ap.add_argument("--variants", default="", help="prologue variants of the copy, e.g. R1P0,R0P32,R1P32 (R: table loads before "
+                    "the policy load; P: touch the policy lines of the workgroup P groups ahead); run for every --blocks geometry")
+    ap.add_argument("--trace-variants", default="", help="variants (of the product geometry) to trace as well")
+    ap.add_argument("--extra-flags", default="", help="extra hipcc flags for the diagnostic kernels, space separated")
     args = ap.parse_args()
 
+    EXTRA_FLAGS.extend(args.extra_flags.split())
     cls = envs.ENVS[args.env]
     if args.compile_only:
         from dynamicprogramming_amd import _native
@@ -342,6 +475,16 @@ def main():
         for blk in sorted({eng.info(11)} | {int(p.split("x")[0]) for p in args.persistent.split(",") if p}):
             for tr_on in (0, 1):
                 print(blk, "trace" if tr_on else "plain", json.dumps(build(text, tr_on, blk, tmp, f"c{blk}_{tr_on}")[1]))
+        fits = [affine_fit(b) for b in tables]
+        print("affine fits", fits)
+        for v in [v for v in args.variants.split(",") if v]:
+            m = re.fullmatch(r"(A?)R(\d)P(\d+)", v)
+            d = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n"
+            if m.group(1):
+                d += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
+                      "#define PT_AFF_B_INIT {" + ",".join(float(f[1]).hex() for f in fits) + "}\n")
+            for tr_on in (0, 1):
+                print(v, tr_on, json.dumps(build(text, tr_on, eng.info(11), tmp, f"v{v}{tr_on}", d)[1]["pt_eval_kernel"]))
         return
     solver = envs.make(args.env, args.bins, device="cuda:0")
     eng = solver._backend.engine
@@ -371,7 +514,7 @@ def main():
         eng.eval_sweep(V.data_ptr(), Vref.data_ptr(), pol.data_ptr(), 0, 0, n, gamma, 0, stream)
 
     lines = [f"# tools/phase_timeline.py  env {args.env} bins {args.bins} states {n}  product geometry {block} x {cpw}  state {args.state}",
-             f"# device {torch.cuda.get_device_name(0)}"]
+             f"# device {torch.cuda.get_device_name(0)}  extra flags {EXTRA_FLAGS}  HIP_FORCE_DEV_KERNARG={os.environ.get('HIP_FORCE_DEV_KERNARG')}"]
     ms_product = timed(product, 20)
     lines.append(f"product kernel (C ABI)              {ms_product:.4f} ms")
     tmp = Path(tempfile.mkdtemp(prefix="pt_"))
@@ -380,8 +523,8 @@ def main():
     count = torch.zeros(1, dtype=torch.int32, device="cuda:0")
     summary = {"product_ms": ms_product}
 
-    def run_variant(tag, trace_on, blk, cpw_v, persistent_w, it0):
-        hsaco, usage = build(src_text, trace_on, blk, tmp, tag)
+    def run_variant(tag, trace_on, blk, cpw_v, persistent_w, it0, defines=""):
+        hsaco, usage = build(src_text, trace_on, blk, tmp, tag, defines)
         mod = Module(hsaco)
         name = "pt_eval_persistent_kernel" if persistent_w else "pt_eval_kernel"
         f = mod.fn(name)
@@ -419,9 +562,27 @@ def main():
     run_variant(f"copy {block}x{cpw}", 0, block, cpw, 0, 0)
     rec = run_variant(f"traced {block}x{cpw}", 1, block, cpw, 0, 0)
     recs = [(f"traced {block}x{cpw} (product schedule)", rec)]
+    geoms = [(block, cpw)]
     for pair in [p for p in args.blocks.split(",") if p]:
         b, c = (int(v) for v in pair.split("x"))
         run_variant(f"copy {b}x{c}", 0, b, c, 0, 0)
+        geoms.append((b, c))
+
+    fits = [affine_fit(np.asarray(b, np.float32)) for b in cls.bins_space(args.bins).values()]
+
+    def defs(v):
+        m = re.fullmatch(r"(A?)R(\d)P(\d+)", v)
+        text = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n"
+        if m.group(1):
+            assert all(f is not None and not f[2] for f in fits), "a bin table of this env is not an exact affine float64 sequence"
+            text += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
+                     "#define PT_AFF_B_INIT {" + ",".join(float(f[1]).hex() for f in fits) + "}\n")
+        return text
+    for v in [v for v in args.variants.split(",") if v]:
+        for b, c in geoms:
+            run_variant(f"{v} {b}x{c}", 0, b, c, 0, 0, defs(v))
+    for v in [v for v in args.trace_variants.split(",") if v]:
+        recs.append((f"{v} {block}x{cpw} traced", run_variant(f"{v} {block}x{cpw} traced", 1, block, cpw, 0, 0, defs(v))))
     first = True
     for pair in [p for p in args.persistent.split(",") if p]:
         b, w = (int(v) for v in pair.split("x"))
