@@ -59,6 +59,7 @@ SIGNATURES = {
     "pi_exchange_plan": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "pi_plan_ranges": (ctypes.c_int64, [_vp, _vp, ctypes.c_int64]),
     "pi_exchange_V": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_eval_sweep_part": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
     "pi_eval_sweeps_sharded": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int,
                                               _vp, _vp]),
     "pi_improve_sweep_sharded": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp]),
@@ -74,11 +75,12 @@ SIGNATURES = {
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
     "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "pi_prepare_mask": (ctypes.c_int, [_vp, _vp, _vp]),
+    "pi_prepare_mask_range": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     "pi_eval_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "pi_eval_end": (ctypes.c_int, [_vp]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 _load_error: Exception | None = None
 
@@ -213,10 +215,15 @@ class Engine:
     def info(self, what: int) -> int:
         return int(lib().pi_info(self._h, what))
 
-    def prepare_mask(self, term, stream=0) -> int:
-        """Let later sweeps of whole-grid batches visit only the non-terminal states of the mask at `term`
-        (0 drops the list); returns the number of live states listed, 0 when the library keeps none."""
-        _check(lib().pi_prepare_mask(self._h, term or None, stream or None), "pi_prepare_mask")
+    def prepare_mask(self, term, stream=0, s_begin=None, s_end=None) -> int:
+        """Let later sweeps of a batch visit only the non-terminal states of the mask at `term` (0 drops the list);
+        [s_begin, s_end) restricts the list to a rank's shard.  Returns the number of live states listed, 0 when
+        the library keeps none."""
+        if s_begin is None:
+            _check(lib().pi_prepare_mask(self._h, term or None, stream or None), "pi_prepare_mask")
+        else:
+            _check(lib().pi_prepare_mask_range(self._h, term or None, int(s_begin), int(s_end), stream or None),
+                   "pi_prepare_mask_range")
         return self.info(16)
 
     def eval_begin(self, policy, term, stream=0) -> int:
@@ -311,6 +318,7 @@ class Engine:
                                       stream or None), "pi_exchange_plan")
         return {"mode": "halo" if info[0] == 2 else "allgather", "recv_elems": int(info[1]),
                 "send_elems": int(info[2]), "send_ranges": int(info[3]), "interior_ranges": int(info[4]),
+                "row_exact": int(lib().pi_comm_info(self._h, 5)) == 1,
                 "reach_units": {1: "planes of dimension 0", 2: "rows (i0, i1)"}.get(
                     int(lib().pi_comm_info(self._h, 4)), "none")}
 
@@ -323,6 +331,11 @@ class Engine:
         buf = (ctypes.c_int64 * (3 * max(int(m), 1)))()
         fn(self._h, buf, int(m))
         return [(int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])) for i in range(int(m))]
+
+    def eval_sweep_part(self, V, Vnew, policy, term, part, gamma, stream=0):
+        """Part 0 (swept first) or 1 (interior) of one sharded evaluation sweep, without the exchange."""
+        _check(lib().pi_eval_sweep_part(self._h, V, Vnew, policy, term or None, int(part), gamma, stream or None),
+               "pi_eval_sweep_part")
 
     def exchange_V(self, V_full, stream=0):
         _check(lib().pi_exchange_V(self._h, V_full, stream or None), "pi_exchange_V")

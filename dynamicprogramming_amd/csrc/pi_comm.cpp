@@ -57,10 +57,19 @@ struct ShardPlan {
     std::vector<Seg> segs;                                   // only those that involve this rank
     std::vector<std::pair<int64_t, int64_t>> send_ranges, interior;
     int64_t recv_elems = 0, send_elems = 0;
-    bool broken = false;            // a sharded sweep failed half-way: streams were drained, plan again
+    bool broken = false;            // a sharded sweep failed half-way: streams were drained; new communicator + plan needed
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    // Row-exact split (grids without terminal states): exactly the rows peers wait for, as an ascending state list
+    // swept by pi_eval_live_kernel in ONE launch, and the rest of the shard as a second list — instead of a few
+    // coarse contiguous ranges that also hold rows nobody waits for (C4 at 8 ranks: 80-100 % of the shard).
+    bool row_exact = false;
+    std::vector<std::pair<int64_t, int64_t>> first_exact, inner_exact;
+    int32_t *d_first = nullptr, *d_inner = nullptr;
+    int64_t n_first = 0, n_inner = 0;
     ~ShardPlan() {
+        if (d_first) (void)hipFree(d_first);
+        if (d_inner) (void)hipFree(d_inner);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -355,8 +364,9 @@ int need_plan(pi_handle* h) {
     if (need_comm(h)) return 1;
     if (!h->plan) return fail("no exchange plan on this handle: call pi_exchange_plan first");
     if (h->plan->broken)
-        return fail("a sharded sweep failed on this handle and its exchange was abandoned: call pi_exchange_plan again "
-                    "(all ranks) before the next sharded sweep");
+        return fail("a sharded sweep failed on this handle and its exchange was abandoned; the communicator is not usable "
+                    "any more (RCCL: aborted; in-process: its group gave up).  Recover on EVERY rank: pi_comm_destroy, a new "
+                    "pi_comm_init (fresh id) / pi_comm_init_local (fresh group name), then pi_exchange_plan");
     return 0;
 }
 
@@ -446,6 +456,7 @@ int pi_comm_info(pi_handle* h, int what) {
         case 2: return std::strcmp(h->comm->kind(), "rccl") == 0 ? 1 : 2;
         case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
         case 4: return h->plan ? h->plan->depth : 0;
+        case 5: return h->plan && h->plan->row_exact ? 1 : 0;
         default: return -1;
     }
 }
@@ -609,6 +620,48 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
             pos = std::max(pos, r.second);
         }
         if (pos < plan->s_end) plan->interior.push_back({pos, plan->s_end});
+        // Row-exact alternative: the union of the rows that travel, nothing merged across gaps.  Taken when the grid
+        // has no terminal states (the list kernel visits listed states only and copies nothing) and it moves at least a
+        // quarter of the coarse swept-first states into the interior; PI_MI355_ROW_EXACT=0 / 1 forces it off / on.
+        {
+            std::vector<std::pair<int64_t, int64_t>> exact;
+            for (const auto& r : cuts) {
+                if (!exact.empty() && r.first <= exact.back().second)
+                    exact.back().second = std::max(exact.back().second, r.second);
+                else
+                    exact.push_back(r);
+            }
+            int64_t exact_states = 0, coarse_states = 0;
+            for (const auto& r : exact) exact_states += r.second - r.first;
+            for (const auto& r : plan->send_ranges) coarse_states += r.second - r.first;
+            int want = -1;
+            if (const char* e = std::getenv("PI_MI355_ROW_EXACT")) want = std::atoi(e) != 0 ? 1 : 0;
+            const bool possible = term == nullptr && !exact.empty() && exact_states < plan->s_end - plan->s_begin;
+            const bool pays = exact.size() > plan->send_ranges.size() && 4 * exact_states <= 3 * coarse_states;
+            if (possible && (want == 1 || (want < 0 && pays))) {
+                std::vector<int32_t> first, inner;
+                first.reserve((size_t)exact_states);
+                inner.reserve((size_t)(plan->s_end - plan->s_begin - exact_states));
+                int64_t at = plan->s_begin;
+                for (const auto& r : exact) {
+                    if (r.first > at) plan->inner_exact.push_back({at, r.first});
+                    for (int64_t q = at; q < r.first; ++q) inner.push_back((int32_t)q);
+                    for (int64_t q = r.first; q < r.second; ++q) first.push_back((int32_t)q);
+                    at = r.second;
+                }
+                if (at < plan->s_end) plan->inner_exact.push_back({at, plan->s_end});
+                for (int64_t q = at; q < plan->s_end; ++q) inner.push_back((int32_t)q);
+                plan->first_exact = exact;
+                plan->n_first = (int64_t)first.size();
+                plan->n_inner = (int64_t)inner.size();
+                PI_HIP(hipMalloc((void**)&plan->d_first, std::max<size_t>(first.size(), 1) * sizeof(int32_t)));
+                PI_HIP(hipMalloc((void**)&plan->d_inner, std::max<size_t>(inner.size(), 1) * sizeof(int32_t)));
+                PI_HIP(hipMemcpyAsync(plan->d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                PI_HIP(hipMemcpyAsync(plan->d_inner, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                PI_HIP(hipStreamSynchronize(st));
+                plan->row_exact = true;
+            }
+        }
         PI_HIP(hipStreamCreateWithFlags(&plan->comm_stream, hipStreamNonBlocking));
         PI_HIP(hipEventCreateWithFlags(&plan->ev_ready, hipEventDisableTiming));
         PI_HIP(hipEventCreateWithFlags(&plan->ev_done, hipEventDisableTiming));
@@ -636,7 +689,10 @@ int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap) {
     if (need_plan(h)) return -1;
     const pi::ShardPlan* p = h->plan;
     std::vector<std::array<int64_t, 3>> all;
-    if (p->halo && p->comm_stream != nullptr) {
+    if (p->halo && p->comm_stream != nullptr && p->row_exact) {
+        for (const auto& r : p->first_exact) all.push_back({0, r.first, r.second});
+        for (const auto& r : p->inner_exact) all.push_back({1, r.first, r.second});
+    } else if (p->halo && p->comm_stream != nullptr) {
         for (const auto& r : p->send_ranges) all.push_back({0, r.first, r.second});
         for (const auto& r : p->interior) all.push_back({1, r.first, r.second});
     } else if (p->s_end > p->s_begin) {
@@ -645,6 +701,27 @@ int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap) {
     for (size_t i = 0; ranges && i < all.size() && (int64_t)i < cap; ++i)
         for (int k = 0; k < 3; ++k) ranges[3 * i + k] = all[i][k];
     return (int64_t)all.size();
+}
+
+// One part of a sharded evaluation sweep WITHOUT the exchange, exactly as pi_eval_sweeps_sharded launches it:
+// part 0 = what peers wait for (swept first), part 1 = the interior.  For measurements and tests: both parts
+// together are one sweep of the shard.  A plan without overlap has everything in part 0.
+int pi_eval_sweep_part(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const uint8_t* term, int part,
+                       float gamma, void* stream) {
+    if (need_plan(h)) return 1;
+    if (!V || !Vnew || !policy || V == Vnew) return fail("bad device pointer");
+    if (part != 0 && part != 1) return fail("part must be 0 (swept first) or 1 (interior)");
+    pi::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const pi::ShardPlan* p = h->plan;
+    if (!(p->halo && p->comm_stream != nullptr))
+        return part == 0 ? pi::launch_eval(h, V, Vnew, policy, term, p->s_begin, p->s_end, gamma, false, st) : 0;
+    if (p->row_exact && term == nullptr)
+        return pi::launch_eval_live(h, V, Vnew, policy, 0, part == 0 ? p->n_first : p->n_inner, gamma, false, st,
+                                    part == 0 ? p->d_first : p->d_inner);
+    for (const auto& r : (part == 0 ? p->send_ranges : p->interior))
+        if (pi::launch_eval(h, V, Vnew, policy, term, r.first, r.second, gamma, false, st)) return 1;
+    return 0;
 }
 
 // Make this rank's freshly written shard of `V_full` visible where the other ranks read it.
@@ -673,7 +750,7 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
     const bool overlap = p->halo && p->comm_stream != nullptr;
     // One launch range of one sweep: the later sweeps of a batch (k >= 1) visit only the range's live states when
     // the handle holds a list for this mask (pi_prepare_mask) — the first one copies the terminal values.
-    const bool live = pi::live_usable(h, term);
+    const bool live = pi::live_usable(h, term, p->s_begin, p->s_end);
     auto sweep = [&](const float* src, float* dst, int64_t a, int64_t b, bool want, int k) -> int {
         if (k >= 1 && live) {
             int64_t first = 0, count = 0;
@@ -688,14 +765,22 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
             float* dst = (k & 1) ? Va : Vb;
             const bool want = k == n_sweeps - 1 && d_delta != nullptr;
             if (overlap) {
-                for (const auto& r : p->send_ranges)
-                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
+                if (p->row_exact && term == nullptr) {
+                    if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_first, gamma, want, st, p->d_first)) return 1;
+                } else {
+                    for (const auto& r : p->send_ranges)
+                        if (sweep(src, dst, r.first, r.second, want, k)) return 1;
+                }
                 PI_HIP(hipEventRecord(p->ev_ready, st));
                 PI_HIP(hipStreamWaitEvent(p->comm_stream, p->ev_ready, 0));
                 if (post_exchange(h, dst, p->comm_stream)) return 1;
                 PI_HIP(hipEventRecord(p->ev_done, p->comm_stream));
-                for (const auto& r : p->interior)
-                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
+                if (p->row_exact && term == nullptr) {
+                    if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_inner, gamma, want, st, p->d_inner)) return 1;
+                } else {
+                    for (const auto& r : p->interior)
+                        if (sweep(src, dst, r.first, r.second, want, k)) return 1;
+                }
                 PI_HIP(hipStreamWaitEvent(st, p->ev_done, 0));
             } else {
                 if (sweep(src, dst, p->s_begin, p->s_end, want, k)) return 1;
@@ -713,7 +798,8 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
     // Failure half-way through the batch: leave a DEFINED state behind.  Drain both streams (a
     // launch or an event may be pending on either), clear the residual slots a finished sweep may
     // have filled, and retire the plan — the peers are at an unknown sweep, so the next sharded call
-    // must be preceded by a collective pi_exchange_plan.  The error of the failing call is kept.
+    // must be preceded by a new communicator and a collective pi_exchange_plan (need_plan says how).  The error of the
+    // failing call is kept.
     const std::string why = pi::last_error();
     if (auto* local = dynamic_cast<LocalComm*>(h->comm)) local->give_up();   // in-process peers stop waiting at once
     if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);

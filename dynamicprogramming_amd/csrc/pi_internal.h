@@ -88,6 +88,7 @@ struct pi_handle {
     const uint8_t* live_term = nullptr;
     int32_t* d_live = nullptr;
     int64_t live_count = 0;
+    int64_t live_lo = 0, live_hi = 0;    // the state range the list covers (pi_prepare_mask_range; the whole grid otherwise)
     // pi_eval_begin .. pi_eval_end: the live states that bootstrap under the policy at eval_policy (device list,
     // capacity live_count); eval_count < 0: none.  eval_holds: buffers every live state of which has been written
     // by a full sweep since pi_eval_begin — a sweep may use the shorter list only between two such buffers.
@@ -115,10 +116,11 @@ int launch_eval(pi_handle* h, const float* V, float* Vnew, const int32_t* policy
                 int64_t s_begin, int64_t s_end, float gamma, bool want_delta, hipStream_t st,
                 bool keep_terminals = false);
 int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
-// The live-state list of pi_prepare_mask.  live_usable: a list is in use and `term` is the mask it was built from.
+// The live-state list of pi_prepare_mask.  live_usable: a list is in use, `term` is the mask it was built from and
+// [s_begin, s_end) lies inside the range it covers.
 // live_span: the run of list entries whose states lie in [s_begin, s_end).  launch_eval_live: one evaluation sweep
 // over `count` list entries from position `first` — for sweeps that need not copy terminal values.
-bool live_usable(const pi_handle* h, const uint8_t* term);
+bool live_usable(const pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end);
 void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
 int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
                      float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);

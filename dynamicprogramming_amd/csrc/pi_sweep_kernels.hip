@@ -370,16 +370,22 @@ __device__ __forceinline__ void pi_state_coords(unsigned int s, const float* lds
 // and because the dispatcher starts workgroups in index order the states in flight on an XCD
 // form one compact, advancing window (measured 5x less traffic past L2 than a grid-stride launch,
 // profiles/r01).  Placement only affects speed.  Returns false when the workgroup has no group.
+// No division by a run-time value here: the host launches exactly PI_NXCD * span workgroups (launch_blocks in
+// pi_api.cpp), so span is gridDim.x / PI_NXCD, and "group g exists" is g * cpw < n_chunks.  The first version
+// computed groups = ceil(n_chunks / cpw) and span = ceil(groups / 8) in 64-bit arithmetic: ~190 scalar instructions
+// per wave in front of its first load, i.e. ~3 000 issue slots of the CU's ONE scalar unit per 1 024-thread workgroup
+// — a fifth of a wave's life on the 80^4 evaluation sweep went by before it had requested anything
+// (tools/phase_timeline.py, profiles/r04/phase_timeline_c4.txt).
 template <int BLOCK>
 __device__ __forceinline__ bool pi_first_chunk(long long count, int cpw, long long& chunk0,
                                                long long& n_chunks) {
+    static_assert((BLOCK & (BLOCK - 1)) == 0, "chunk size must be a power of two (shift, not divide)");
     n_chunks = (count + BLOCK - 1) / BLOCK;
-    const long long groups = (n_chunks + cpw - 1) / cpw;
-    const long long span = (groups + PI_NXCD - 1) / PI_NXCD;
-    const long long x = blockIdx.x % PI_NXCD, j = blockIdx.x / PI_NXCD;
-    const long long g = x * span + j;
-    chunk0 = g * cpw;
-    return j < span && g < groups;
+    const unsigned int span = gridDim.x / PI_NXCD;
+    const unsigned int x = blockIdx.x % PI_NXCD, j = blockIdx.x / PI_NXCD;
+    const unsigned int g = x * span + j;
+    chunk0 = (long long)g * (long long)cpw;
+    return chunk0 < n_chunks;
 }
 
 // Bin tables and actions -> LDS.  All loads are issued before the first store.

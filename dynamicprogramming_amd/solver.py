@@ -93,8 +93,8 @@ class HipSweepBackend:
         (the kernels then read no mask and, on sweeps without a residual, no old value either)."""
         return 0 if term is None else term.data_ptr()
 
-    def prepare_mask(self, term) -> int:
-        return self.engine.prepare_mask(self._ptr(term), self._stream())
+    def prepare_mask(self, term, s_begin=None, s_end=None) -> int:
+        return self.engine.prepare_mask(self._ptr(term), self._stream(), s_begin, s_end)
 
     def eval_begin(self, policy, term) -> int:
         return self.engine.eval_begin(policy.data_ptr(), self._ptr(term), self._stream())
@@ -296,10 +296,13 @@ class _CudaPolicyIterationBase(abc.ABC):
         self._term_arg = self.d_terminal_mask if (terminal_mask is not None and terminal_mask.any()) else None
         # the mask is fixed from here on (as in the reference): the library may list the live states once
         # and visit only those in the later sweeps of an evaluation batch and in the improvement sweeps
-        # (big grids whose terminal regions cut through many waves; every rank lists the whole grid and
-        # sweeps the part of the list that lies in its launch ranges)
+        # (big grids whose terminal regions cut through many waves; a rank of a sharded run lists its own shard
+        # only — the states its launches visit)
         if self._term_arg is not None and hasattr(self._backend, "prepare_mask"):
-            self._backend.prepare_mask(self._term_arg)
+            if self._comm is not None:
+                self._backend.prepare_mask(self._term_arg, self._s_begin, self._s_end)
+            else:
+                self._backend.prepare_mask(self._term_arg)
         if self._comm is not None:
             self._comm.plan(self)
             if self._comm.halo_elems >= 0:

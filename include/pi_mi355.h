@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 6
+#define PI_MI355_ABI_VERSION 7
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -121,10 +121,13 @@ int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
  * only when at least 3 % of the grid's lane slots would be idle otherwise and the grid has 2^20 states or more
  * (pi_info 16 = length of the list in use, 0 = none).  Results are identical with and without it.
  * Contract: the bytes behind d_term must not change while the list is in use; call again after changing
- * them, or with d_term == NULL to drop the list.  Calls given another mask pointer ignore the list.  The list
- * covers the whole grid on every rank (4 B per live state on the device, n / 8 + n / 8 bytes of index on the host).
+ * them, or with d_term == NULL to drop the list.  Calls given another mask pointer, or a state range that is not
+ * inside the listed one, ignore the list.  pi_prepare_mask lists the whole grid (4 B per live state on the device,
+ * n / 8 + n / 8 bytes of index on the host); pi_prepare_mask_range lists [s_begin, s_end) only — what a rank of a
+ * sharded run needs (its launches never leave its shard): 1 / world of the list, of the index and of the host pass.
  */
 int pi_prepare_mask(pi_handle* h, const uint8_t* d_term, void* stream);
+int pi_prepare_mask_range(pi_handle* h, const uint8_t* d_term, int64_t s_begin, int64_t s_end, void* stream);
 
 /*
  * Optional bracket around one policy_evaluation (:300-336), for handles with a live-state list: under a FIXED
@@ -252,6 +255,17 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
  * (peers wait for rows inside it), 1 = interior (swept while the halo travels).  Returns how many
  * there are (-1 without a plan).  A plan without overlap reports the shard as one kind-0 range. */
 int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap);
+/*
+ * One part of a sharded evaluation sweep WITHOUT the exchange, launched exactly as pi_eval_sweeps_sharded launches it:
+ * part 0 = what the peers wait for (swept first), part 1 = the interior; both together are one sweep of the shard.
+ * On grids without terminal states the plan may be ROW-EXACT (pi_comm_info(h, 5) == 1; PI_MI355_ROW_EXACT=0 / 1
+ * forces it): part 0 is then the list of exactly the rows that travel, swept in one launch of the list kernel, and
+ * part 1 the list of all other states of the shard, instead of a few contiguous ranges that also hold rows nobody
+ * waits for.  No reference counterpart (src/cuda_policy_iteration.py:300-336 is a single-device loop); for measurements
+ * and tests.
+ */
+int pi_eval_sweep_part(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const uint8_t* term, int part,
+                       float gamma, void* stream);
 /* Make this rank's freshly written shard of V_full visible where the other ranks read it. */
 int pi_exchange_V(pi_handle* h, float* V_full, void* stream);
 /*

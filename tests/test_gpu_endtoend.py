@@ -1102,3 +1102,232 @@ def test_headline_sweep_times_stay_in_range(cuda_device):
     s._backend.close()
     assert eval_ms < 0.56, eval_ms
     assert improve_ms < 3.2, improve_ms
+
+
+@pytest.mark.parametrize("world,name,shape", [(2, "double_pendulum_swingup", (14, 9, 11, 8)), (3, "cartpole_swingup", (18, 7, 9, 8))])
+def test_bench_self_check_of_sharded_sweeps(world, name, shape, cuda_device, monkeypatch):
+    """bench.py's N-rank self-check (`sharded_equals_unsharded`: 2 evaluation + 1 improvement sweeps through the sharded
+    driver against the same sweeps over the whole grid, torch.equal) — run here with logical ranks over the in-process
+    transport, since a development box has one GPU: it must pass on the real driver and FAIL when the exchange delivers
+    nothing (a halo that is never sent is exactly what a first RCCL run could get wrong)."""
+    import importlib.util
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    spec = importlib.util.spec_from_file_location("bench_under_test", H.GOLDEN.parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("PI_MI355_EXCHANGE", "halo")
+    cls = envs.ENVS[name]
+    gamma = float(np.float32(cls.CONFIG["gamma"]))
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32)
+    P0 = torch.randint(0, len(cls.ACTIONS), (n,), generator=gen, dtype=torch.int32)
+
+    class Dist:                                        # every logical rank reaches its own verdict; MIN over one value
+        class ReduceOp:
+            MIN = "min"
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+
+    def run(broken):
+        group = f"bench-check-{uuid.uuid4().hex}"
+        out, errors = [None] * world, []
+
+        def rank_main(r):
+            try:
+                stream = torch.cuda.Stream(device=cuda_device)
+                with torch.cuda.stream(stream):
+                    s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cls.CONFIG), device=cuda_device,
+                            transport=T.NativeTransport.local(r, world, group))
+                    s.d_value_function[:n].copy_(V0)
+                    s.d_new_value_function.copy_(s.d_value_function)
+                    s.d_policy[:n].copy_(P0)
+                    if broken:                         # the exchange "succeeds" but moves nothing
+                        real = s._comm.engine.eval_sweeps_sharded
+
+                        def no_exchange(Va, Vb, policy, term, g, k, d_delta=0, st=0):
+                            for i in range(k):
+                                src, dst = (Vb, Va) if (i & 1) else (Va, Vb)
+                                s._backend.engine.eval_sweep(src, dst, policy, term, s._s_begin, s._s_end, g,
+                                                             d_delta if i == k - 1 else 0, st)
+                        s._comm.engine.eval_sweeps_sharded = no_exchange
+                    out[r] = bench.sharded_equals_unsharded(s, s._backend.engine, gamma, torch, Dist)
+                    # the solver's state is what it was before the check
+                    assert torch.equal(s.d_value_function[:n].cpu(), V0) and torch.equal(s.d_policy[:n].cpu(), P0)
+                    torch.cuda.synchronize()
+                    s._backend.close()
+            except Exception as exc:  # noqa: BLE001
+                errors.append((r, repr(exc)))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        return out
+
+    good = run(False)
+    assert all(o["ok"] and o["V"] and o["policy"] and o["residual"] and o["changed"] for o in good), good
+    bad = run(True)
+    assert not any(o["ok"] for o in bad) and not all(o["V"] for o in bad), bad
+
+
+@pytest.mark.parametrize("world,name,shape", [(8, "double_pendulum_swingup", (40, 12, 8, 6)), (4, "double_pendulum_swingup", (24, 9, 7, 5)),
+                                               (3, "pendulum", (60, 33))])
+def test_row_exact_swept_first_lists(world, name, shape, cuda_device, monkeypatch):
+    """Row-exact exchange plans (grids without terminal states, PI_MI355_ROW_EXACT): what is swept first is exactly the
+    rows that travel — as a state list swept by the list kernel in one launch — and the interior is the rest of the
+    shard.  Checked with logical ranks over the in-process transport: the two parts tile the shard, every state a peer
+    receives lies in part 0, part 0 + part 1 through pi_eval_sweep_part equal one plain sweep of the shard bit for bit,
+    and whole run()s equal the single-rank run.  The coarse plan of the same grid sweeps MORE states first."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_EXCHANGE", "halo")
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 2, "max_eval_iter": 40}
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
+    single.run()
+    n = single.n_states
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32)
+    P0 = torch.randint(0, len(cls.ACTIONS), (n,), generator=gen, dtype=torch.int32)
+    gamma = float(np.float32(cls.CONFIG["gamma"]))
+
+    def run(row_exact):
+        monkeypatch.setenv("PI_MI355_ROW_EXACT", "1" if row_exact else "0")
+        group = f"rowexact-{uuid.uuid4().hex}"
+        out, errors = [None] * world, []
+
+        def rank_main(r):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+                    s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device,
+                            transport=T.NativeTransport.local(r, world, group))
+                    eng, info, ranges = s._backend.engine, dict(s._comm.info), s._backend.engine.plan_ranges()
+                    a, b = s._s_begin, s._s_end
+                    # parts of one sweep against the plain range sweep of the shard
+                    dV, dP = V0.to(cuda_device), P0.to(cuda_device)
+                    whole, parts = torch.zeros_like(dV), torch.zeros_like(dV)
+                    st = torch.cuda.current_stream().cuda_stream
+                    eng.eval_sweep(dV.data_ptr(), whole.data_ptr(), dP.data_ptr(), 0, a, b, gamma, 0, st)
+                    eng.eval_sweep_part(dV.data_ptr(), parts.data_ptr(), dP.data_ptr(), 0, 0, gamma, st)
+                    torch.cuda.synchronize()
+                    first_only = parts.clone()
+                    eng.eval_sweep_part(dV.data_ptr(), parts.data_ptr(), dP.data_ptr(), 0, 1, gamma, st)
+                    torch.cuda.synchronize()
+                    same = bool(torch.equal(whole, parts))
+                    touched_first = int((first_only != 0).sum().item())
+                    s.run()
+                    out[r] = dict(info=info, ranges=ranges, shard=(a, b), same=same, touched_first=touched_first,
+                                  V=s.value_function, P=s.policy, sweeps=list(s.stats["sweeps_per_iter"]))
+            except Exception as exc:  # noqa: BLE001
+                errors.append((r, repr(exc)))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        return out
+
+    exact, coarse = run(True), run(False)
+    for r, (e, c) in enumerate(zip(exact, coarse)):
+        assert e["info"]["mode"] == "halo" and e["info"]["row_exact"] and not c["info"]["row_exact"]
+        a, b = e["shard"]
+        spans = sorted((lo, hi) for _, lo, hi in e["ranges"])
+        assert spans[0][0] == a and spans[-1][1] == b and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+        first = sum(hi - lo for k, lo, hi in e["ranges"] if k == 0)
+        assert first == e["info"]["send_elems"] or first <= e["info"]["send_elems"]     # rows sent to several peers count once here
+        assert 0 < first < b - a
+        assert abs(e["touched_first"] - first) <= first * 1e-3 + 2                      # part 0 wrote those states (V' == 0 is rare)
+        assert first <= sum(hi - lo for k, lo, hi in c["ranges"] if k == 0)             # never more than the coarse plan
+        assert e["same"] and c["same"]
+        H.assert_bits_equal(e["V"], single.value_function, f"rank {r} V (row-exact)")
+        assert np.array_equal(e["P"], single.policy) and e["sweeps"] == single.stats["sweeps_per_iter"]
+    total_exact = sum(sum(hi - lo for k, lo, hi in e["ranges"] if k == 0) for e in exact)
+    total_coarse = sum(sum(hi - lo for k, lo, hi in c["ranges"] if k == 0) for c in coarse)
+    assert total_exact <= total_coarse
+    if cls._D >= 4:                                     # rows (i0, i1): the coarse plan merges across rows nobody waits for
+        assert total_exact < total_coarse
+
+
+def test_recovery_after_an_abandoned_sharded_batch(cuda_device, monkeypatch):
+    """The documented recovery path (include/pi_mi355.h): a sharded batch that fails half-way — here
+    because the peer never takes part — is abandoned with a message, the handle then refuses sharded sweeps and says
+    what to do, and after pi_comm_destroy + a new communicator + a collective pi_exchange_plan on every rank the same
+    handles sweep again, bit-identical to a single-rank solver."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_EXCHANGE", "halo")
+    monkeypatch.setenv("PI_MI355_COMM_TIMEOUT", "2")
+    name, shape, world = "double_pendulum_swingup", (14, 9, 11, 8), 2
+    cls = envs.ENVS[name]
+    cfg = envs.CudaPIConfig(**cls.CONFIG)
+    gamma = float(np.float32(cfg.gamma))
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32)
+    P0 = torch.randint(0, len(cls.ACTIONS), (n,), generator=gen, dtype=torch.int32)
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device, transport=False)
+    single.d_value_function[:n].copy_(V0)
+    single.d_new_value_function.copy_(single.d_value_function)
+    single.d_policy[:n].copy_(P0)
+    single._evaluation_sweeps(3, gamma)
+    torch.cuda.synchronize()
+    V_ref = single.d_value_function[:n].clone()
+
+    first, second = f"doomed-{uuid.uuid4().hex}", f"fresh-{uuid.uuid4().hex}"
+    failed, rebuilt = threading.Event(), threading.Barrier(world, timeout=120)
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+                s = cls(H.env_bins_space(name, shape), cls.ACTIONS, cfg, device=cuda_device,
+                        transport=T.NativeTransport.local(r, world, first))
+                s.d_value_function[:n].copy_(V0)
+                s.d_new_value_function.copy_(s.d_value_function)
+                s.d_policy[:n].copy_(P0)
+                torch.cuda.synchronize()
+                if r == 0:
+                    with pytest.raises(_native.NativeError, match="abandoned"):
+                        s._evaluation_sweeps(3, gamma)             # rank 1 never posts its rows
+                    with pytest.raises(_native.NativeError, match="pi_comm_destroy"):
+                        s._evaluation_sweeps(1, gamma)             # refuses, and says how to recover
+                    failed.set()
+                else:
+                    assert failed.wait(timeout=120)
+                # recovery, every rank: destroy, new communicator, new plan
+                eng = s._backend.engine
+                eng.comm_destroy()
+                rebuilt.wait()
+                eng.comm_init_local(r, world, second)
+                s._comm.plan(s)
+                s.d_value_function[:n].copy_(V0)
+                s.d_new_value_function.copy_(s.d_value_function)
+                s._evaluation_sweeps(3, gamma)
+                torch.cuda.synchronize()
+                out[r] = bool(torch.equal(s.d_value_function[s._s_begin:s._s_end], V_ref[s._s_begin:s._s_end]))
+                s._backend.close()
+        except BaseException as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+            failed.set()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert out == [True] * world

@@ -306,6 +306,12 @@ def test_inference_kernel_builds_without_a_gpu_and_validates_arguments(tmp_path)
         _native.InferenceEngine([0, 0], [1, 1], [3, 3], [3, 1], bits * 2, device=-1, cache_dir=None)
     with pytest.raises(_native.NativeError, match="exceed bounds_low"):
         _native.InferenceEngine([0, 1], [1, 1], [3, 3], [3, 1], bits, device=-1, cache_dir=None)
+    # strides that do not belong to the grid would make the kernel read policy[flat] out of bounds
+    with pytest.raises(_native.NativeError, match="strides must be positive"):
+        _native.InferenceEngine([0, 0], [1, 1], [3, 3], [3, -1], bits, device=-1, cache_dir=None)
+    with pytest.raises(_native.NativeError, match="outside the policy table"):
+        _native.InferenceEngine([0, 0], [1, 1], [3, 4], [5, 1], bits, device=-1, cache_dir=None)      # another grid's strides
+    _native.InferenceEngine([0, 0], [1, 1], [3, 4], [1, 3], bits, device=-1, cache_dir=tmp_path).close()   # column-major is fine
     import torch
     if not torch.cuda.is_available():
         from utils.barycentric import DevicePolicy

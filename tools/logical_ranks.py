@@ -86,6 +86,7 @@ def rank_main(r):
             same_P = bool(torch.equal(s.d_policy[a:b], P_ref[a:b]))
             ok_scalars = int(s._d_changed.item()) == changed_ref and float(s._d_delta.item()) == delta_ref
             out[r] = {"rank": r, "states": b - a, "mode": info["mode"], "reach_units": info["reach_units"],
+                      "row_exact_plan": info.get("row_exact"),
                       "bytes_received_per_sweep": 4 * info["recv_elems"], "bytes_sent_per_sweep": 4 * info["send_elems"],
                       "ranges": ranges, "bit_identical_V": same_V, "bit_identical_policy": same_P,
                       "reduced_scalars_equal": ok_scalars, "_solver": s}
@@ -113,12 +114,12 @@ for o in out:
         rs = [(a, b) for k, a, b in o["ranges"] if k == kind]
         if not rs:
             continue
+        term_ptr = s._backend._ptr(s._mask_arg())
         for rep in range(2):                                # first repetition warms up
             e0.record()
-            for _ in range(5):
-                for a, b in rs:
-                    eng.eval_sweep(s.d_value_function.data_ptr(), s.d_new_value_function.data_ptr(),
-                                   s.d_policy.data_ptr(), s.d_terminal_mask.data_ptr(), a, b, gamma, 0, st)
+            for _ in range(5):                              # exactly the launches the sharded driver makes for this part
+                eng.eval_sweep_part(s.d_value_function.data_ptr(), s.d_new_value_function.data_ptr(),
+                                    s.d_policy.data_ptr(), term_ptr, kind, gamma, st)
             e1.record()
             e1.synchronize()
         parts[kind] = e0.elapsed_time(e1) / 5
@@ -137,6 +138,7 @@ for o in out:
     o["first_ms"], o["interior_ms"] = parts[0], parts[1]
     o["first_later_sweeps_ms"], o["interior_later_sweeps_ms"] = later[0], later[1]
     o["live_states_listed"] = eng.info(16)
+    o["row_exact"] = bool(eng.comm_info(5) == 1)
     o["first_launches"] = sum(1 for k, _, _ in o["ranges"] if k == 0)
     o["interior_launches"] = sum(1 for k, _, _ in o["ranges"] if k == 1)
     o["first_states"] = sum(b - a for k, a, b in o["ranges"] if k == 0)

@@ -124,6 +124,10 @@ int main(int argc, char** argv) {
         bits[5] = 2;
         CHECK(pi_infer_create(-1, 4, lo, hi, shape, strides, bits, 16, cache) == nullptr);
         CHECK(pi_infer_create(-1, 4, lo, hi, shape, strides, bits, 8, cache) == nullptr);
+        bits[5] = 0;
+        const int32_t foreign[4] = {400, 20, 5, 1}, negative[4] = {72, 18, -3, 1};     // another grid's / negative strides
+        CHECK(pi_infer_create(-1, 4, lo, hi, shape, foreign, bits, 16, cache) == nullptr);
+        CHECK(pi_infer_create(-1, 4, lo, hi, shape, negative, bits, 16, cache) == nullptr);
     }
     pi_destroy(nullptr);
     pi_infer_destroy(nullptr);

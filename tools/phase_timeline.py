@@ -50,6 +50,21 @@ PT_KERNELS = r'''
 #ifndef PT_AFFINE
 #define PT_AFFINE 0
 #endif
+// PT_WPRIO: issue priority by position in the workgroup.  The arbiter prefers the oldest wave, so the 16 waves of a
+// workgroup drift apart in index order and the first ones leave their slots empty for thousands of cycles before the
+// last one frees the workgroup's resources.  1: base priority = wave / 4 (0..3), 3 while the gather is in flight;
+// 2: base = wave / 8 (0..1), 2 while the gather is in flight; 3: base = wave / 4, no gather window.
+#ifndef PT_WPRIO
+#define PT_WPRIO 0
+#endif
+__device__ __forceinline__ void pt_setprio(int level) {
+    switch (level) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 #if PT_AFFINE
 // Grid coordinates without the LDS copy of the bin tables: x_d = (float)((double)i_d * step_d + start_d), two float64
 // operations and one conversion, verified on the host to reproduce EVERY float32 entry of the table (the tables are
@@ -103,7 +118,14 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
     PT_STAMP(21);
 #endif
     const unsigned int tid = threadIdx.x;
-    long long c, c_end, c_step;
+#if PT_WPRIO
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int waves = PI_BLOCK_EVAL / 64;
+    const int base_prio = PT_WPRIO == 2 ? (wave_in_wg * 2) / waves : (wave_in_wg * 4) / waves;
+    pt_setprio(base_prio);
+#endif
+    long long c, c_step;
+    long long c_end;
     if (PERSISTENT) {
         const long long n_chunks = (s_end - s_begin + PI_BLOCK_EVAL - 1) / PI_BLOCK_EVAL;
         const long long span = (n_chunks + PI_NXCD - 1) / PI_NXCD;
@@ -213,12 +235,22 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
 #if PT_TRACE
             if (rec) PT_STAMP2(3);                // D: the 2^(D-1) corner loads issued
 #endif
+#if PT_WPRIO == 0
             __builtin_amdgcn_s_setprio(1);
+#elif PT_WPRIO == 1
+            __builtin_amdgcn_s_setprio(3);
+#elif PT_WPRIO == 2
+            __builtin_amdgcn_s_setprio(2);
+#endif
 #if PT_TRACE
             if (rec) { PT_WAIT_ALL(); PT_STAMP2(4); }                              // E: corner values back
 #endif
             e = pi_combine_corners(vp, fr);
+#if PT_WPRIO == 0
             __builtin_amdgcn_s_setprio(0);
+#elif PT_WPRIO != 3
+            pt_setprio(base_prio);
+#endif
         }
         const float nv = reward + gamma * e;
         if (tid == lane_c) pi_store_lane(Vn + sb_c, lane_c, nv);
@@ -380,6 +412,22 @@ def fold(rec: np.ndarray, lines: list, label: str):
                  f"({len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist())))} CUs), chunks per wave {np.median(its):.0f}")
     lines.append(f"wave lifetime (entry -> end), shader cycles: median {np.median(life):.0f}  p10 {np.percentile(life, 10):.0f}  "
                  f"p90 {np.percentile(life, 90):.0f}")
+    wv = rec[:, 18]
+    if wv.max() > 0:
+        trend = [f"{int(np.median(life[wv == w])):d}" for w in range(int(wv.max()) + 1) if (wv == w).any()]
+        lines.append("median lifetime by wave index in the workgroup: " + " ".join(trend))
+        endrel = {}
+        for b in np.unique(rec[:, 17])[:4000]:
+            idx = np.flatnonzero(rec[:, 17] == b)
+            if len(idx) == int(wv.max()) + 1:
+                e = ((rec[idx, 16].astype(np.int64) - rec[idx, 2].astype(np.int64).min()) & 0xFFFFFFFF)
+                endrel.setdefault("spread", []).append(int(e.max() - e.min()))
+                endrel.setdefault("wg_life", []).append(int(e.max()))
+                endrel.setdefault("idle", []).append(float((e.max() - e).mean()))
+        if endrel:
+            lines.append(f"per workgroup: lifetime (first entry -> last end) median {np.median(endrel['wg_life']):.0f}, end spread median "
+                         f"{np.median(endrel['spread']):.0f}, mean cycles a finished wave's slot waits for the workgroup's last wave "
+                         f"{np.mean(endrel['idle']):.0f}")
     lines.append(f"entry -> kernel arguments loaded: median {np.median(d(2, 21)):.0f}  p90 {np.percentile(d(2, 21), 90):.0f}")
     lines.append(f"entry -> tables staged + barrier passed: median {np.median(d(2, 3)):.0f}  p90 {np.percentile(d(2, 3), 90):.0f}")
     tot = np.zeros(len(rec))
@@ -478,8 +526,8 @@ def main():
         fits = [affine_fit(b) for b in tables]
         print("affine fits", fits)
         for v in [v for v in args.variants.split(",") if v]:
-            m = re.fullmatch(r"(A?)R(\d)P(\d+)", v)
-            d = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n"
+            m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
+            d = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
             if m.group(1):
                 d += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
                       "#define PT_AFF_B_INIT {" + ",".join(float(f[1]).hex() for f in fits) + "}\n")
@@ -571,8 +619,8 @@ def main():
     fits = [affine_fit(np.asarray(b, np.float32)) for b in cls.bins_space(args.bins).values()]
 
     def defs(v):
-        m = re.fullmatch(r"(A?)R(\d)P(\d+)", v)
-        text = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n"
+        m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
+        text = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
         if m.group(1):
             assert all(f is not None and not f[2] for f in fits), "a bin table of this env is not an exact affine float64 sequence"
             text += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
