@@ -100,7 +100,7 @@ def test_the_references_literal_plugin_strings_compile_unchanged(name, tmp_path)
     geometry assumes.  Build container only (the reference does not travel); nothing is written into the tree."""
     from oracle import build_ref
     if not build_ref.available():
-        pytest.skip("/root/reference is not present (GPU box): literal reference strings cannot be read")
+        pytest.skip("the reference tree is not present (GPU box): literal reference strings cannot be read")
     text = build_ref.dynamics_text(name)
     assert "step_dynamics" in text and "__device__" in text
     cls = envs.ENVS[name]
