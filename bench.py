@@ -160,8 +160,18 @@ def cpu_baseline(env: str, bins: int, sample_states: int, seed: int = 0) -> dict
     mid, dt_mid, stride_mid = (many, dt_many, stride_many) if mid_threads == all_cores else run(max(m_all // 2, 1), mid_threads)
     one, dt_one, stride_one = run(max(m_all // 16, 1), 1)
     chk.set_threads(checker_threads)
-    return {"value": many, "unit": "backups/s", "cores": all_cores, "kind": "port",
-            "value_16_threads": mid, "threads_16": mid_threads,
+    quota = None
+    try:                                                    # cgroup v2 CPU quota of this box's share, if any
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    # `value` / `cores`: the faster of the two multi-thread runs with the threads it used (on a box whose CPU share is
+    # smaller than its affinity mask, one thread per listed core oversubscribes the share and is slower)
+    best, best_threads = (many, all_cores) if many >= mid else (mid, mid_threads)
+    return {"value": best, "unit": "backups/s", "cores": best_threads, "kind": "port",
+            "value_all_affinity_threads": many, "affinity_threads": all_cores,
+            "value_16_threads": mid, "threads_16": mid_threads, "cgroup_cpu_quota_cores": quota,
             "value_1_thread": one, "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
             "numpy_reference_c1": numpy_reference_c1(),
             "sample": f"one step (10 eval + 1 improve sweeps) over every {stride_many}-th state of the same "

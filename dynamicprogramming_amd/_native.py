@@ -172,7 +172,10 @@ def plan_segments(world, g0, stride0, n_states, per, reach) -> np.ndarray:
 class Engine:
     """One pi_handle: a grid + action set + (after compile) its specialised kernels."""
 
-    def __init__(self, D, grid_shape, lo, hi, bins, actions, device: int = -1):
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, device: int = -1, order=None):
+        """`order` (optional): memory order of the dimensions — order[k] is the user dimension stored as memory
+        dimension k, 0 = slowest (pi_set_option 4).  Every flat state index and every device array of this engine
+        is then in that order (`to_memory` / `to_user` convert whole-grid arrays); results do not depend on it."""
         L = lib()
         self.D = int(D)
         self._shape = np.ascontiguousarray(grid_shape, dtype=np.int32)
@@ -190,6 +193,34 @@ class Engine:
         self.device = int(device)
         self.n_states = int(L.pi_info(self._h, 0))
         self.compile_log = ""
+        self.order = tuple(range(self.D))
+        if order is not None and tuple(int(d) for d in order) != self.order:
+            order = tuple(int(d) for d in order)
+            if sorted(order) != list(range(self.D)):
+                raise NativeError(f"memory order {order} is not a permutation of the {self.D} dimensions")
+            self.set_option(4, sum(d << (3 * k) for k, d in enumerate(order)))
+            self.order = order
+
+    # -- memory order of the dimensions ----------------------------------------
+    def to_memory(self, a):
+        """A whole-grid array (numpy or torch, n_states entries, the user's row-major order) in this engine's
+        memory order.  The identity when no order was given."""
+        if self.order == tuple(range(self.D)):
+            return a
+        shape = [int(g) for g in self._shape]
+        b = a.reshape(shape)
+        b = b.permute(*self.order) if hasattr(b, "permute") else b.transpose(self.order)
+        return b.reshape(-1) if not hasattr(b, "contiguous") else b.contiguous().reshape(-1)
+
+    def to_user(self, a):
+        """The inverse of `to_memory`."""
+        if self.order == tuple(range(self.D)):
+            return a
+        shape = [int(self._shape[d]) for d in self.order]
+        inv = [self.order.index(d) for d in range(self.D)]
+        b = a.reshape(shape)
+        b = b.permute(*inv) if hasattr(b, "permute") else b.transpose(inv)
+        return b.reshape(-1) if not hasattr(b, "contiguous") else b.contiguous().reshape(-1)
 
     # -- compilation ---------------------------------------------------------
     def kernel_source(self, dynamics_src: str) -> str:

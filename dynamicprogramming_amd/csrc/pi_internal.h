@@ -63,6 +63,11 @@ struct pi_handle {
     std::vector<int32_t> shape;
     std::vector<float> lo, span, rcp;
     std::vector<int> fastdiv;
+    // Memory order of the dimensions (pi_set_option 4): memory dimension k (0 = slowest) is user dimension user_of_mem[k];
+    // user dimension d lives in memory dimension mem_of_user[d].  shape / lo / span / rcp / fastdiv / the bin tables
+    // are kept in MEMORY order; every flat state index of the C ABI is an index in that order.  Identity by default.
+    std::vector<int> mem_of_user, user_of_mem;
+    bool compiled = false;               // pi_compile has run: the memory order can no longer change
     std::vector<float> tab;              // actions | bins_0 | bins_1 | ...
     float* d_tab = nullptr;
     unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed

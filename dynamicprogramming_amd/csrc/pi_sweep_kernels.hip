@@ -23,17 +23,23 @@
 // sweep, an LDS-resident kernel that runs whole batches of sweeps (or a whole policy evaluation)
 // of a small grid in one launch, and the reach probes the multi-GPU exchange is planned from.
 //
-// What bounds these kernels on MI355X, and what the code does about it (DESIGN.md sections 4 and 5,
-// profiles/r03): in 4-D and 6-D the evaluation sweep is bound by the vector L1 (TCP) of its divergent corner
-// gather — a wave-wide 8-byte load costs max(16, distinct 128-byte lines) tag look-ups and every line that
-// misses waits ~200-250 cycles for L2 — with the VALU at 0.49 (80^4) / 0.23 (25^6) of its 1 228.8 G
-// instructions/s and HBM at 0.27 / 0.18 of 8 TB/s; the improvement sweep is co-limited by VALU issue (0.54)
-// and the same unit.  VALU issue is ~2.2 cycles per wave64 instruction per SIMD for ANY mix that is at
-// least half fp32 fma/mul/add: compares, selects, min/max, conversions, shifts, integer multiplies and
-// the v_div_* helpers cost 4.15 cycles (transcendentals 8.15) only in a stream of nothing else — mixed in,
-// clustered or not, they are hidden (tools/valu_issue_bench.hip, profiles/r03/valu_issue.txt).  So the
-// code keeps the instruction count low, keeps every load in flight early, and touches as few lines per
-// wave as the dynamics allow:
+// What bounds these kernels on MI355X, and what the code does about it (DESIGN.md sections 4 and 5, profiles/r04):
+// no single unit.  On the 80^4 evaluation sweep the most utilised one is VALU issue at ~0.5 of the guide's 1 228.8 G
+// wave64 instructions/s (0.67 of the 950 G/s the chip sustains); its vector loads need ~0.4 of the launch at the
+// 16-cycle-per-load floor of the vector-memory path, HBM-side traffic is ~0.25 of 8 TB/s; in 6-D the load floor leads
+// (0.56).  Why the units' times ADD instead of overlapping (per-wave timeline, tools/phase_timeline.py,
+// profiles/r04/phase_timeline_c4.txt): a wave's phases are one dependent chain — inputs, ~400 VALU instructions of
+// dynamics and cell search that issue one per ~6 cycles (latency-, not throughput-bound: a lone wave cannot issue
+// faster than one per ~5), 2^(D-1) loads that queue at the TA, a ~1 200-cycle round trip, the fmaf chain — and only 5.6
+// of a SIMD's 8 wave slots are occupied on average (the arbiter serves a workgroup's waves oldest-first, so they finish
+// over a 6 000-cycle window and a 1 024-thread workgroup frees its slots only as a whole), of which ~2 are in an
+// arithmetic phase at any time: 2 waves x 1/6 instruction per cycle is the VALU utilisation measured.  More waves per
+// SIMD do not exist, fewer are slower (profiles/r03/negative_results.txt (8)); persistent workgroups, prefetching the
+// next workgroup's inputs, dropping the LDS table and its barrier, and per-wave priorities were all built and are
+// slower (profiles/r04/negative_results.txt).  VALU issue is ~2.2 cycles per wave64 instruction per SIMD for ANY
+// mix that is at least half fp32 fma/mul/add (tools/valu_issue_bench.hip, profiles/r03/valu_issue.txt).  So the
+// code keeps the instruction count low — in the SCALAR prologue too: a wave requests nothing before it — keeps every
+// load in flight early, and touches as few lines per wave as the dynamics allow:
 //   * the interpolation's IEEE divisions (s - lo) / (hi - lo) have a per-dimension constant
 //     divisor: they run as a * rcp, one residual fma and one correction fma — bit-identical to
 //     the IEEE quotient for every dividend in [2^-40, 2^40], which the host PROVES per divisor
@@ -102,7 +108,24 @@ constexpr int PI_FASTDIV[PI_D] = PI_FASTDIV_INIT;
 // V offsets as 32-bit BYTE offsets (4 n < 2^32) — otherwise 64-bit element indexing.
 constexpr bool PI_OFF32 = PI_GRID.n * 4 < (1LL << 32);
 
-// Which dimension-bit of the partial-product index a corner number selects.
+// Memory order of the dimensions (pi_set_option 4).  Everything above — PI_GRID, PI_LO, ... and every flat state
+// index — is in MEMORY order: memory dimension 0 is the slowest, PI_D - 1 the one lanes run along.  The USER's
+// dimension d (the d-th argument of step_dynamics, the d-th key of bins_space) is memory dimension PI_MEM_OF[d];
+// the identity unless the host chose another order for this grid.  Where a state lives is all the order changes:
+// the arithmetic that has an order of its own — corner weights as products over the dimensions, the fmaf chain
+// over the corners — stays in the USER's order, so results do not depend on it bit for bit.
+#ifndef PI_MEM_OF_INIT
+#if PI_D == 2
+#define PI_MEM_OF_INIT {0, 1}
+#elif PI_D == 4
+#define PI_MEM_OF_INIT {0, 1, 2, 3}
+#else
+#define PI_MEM_OF_INIT {0, 1, 2, 3, 4, 5}
+#endif
+#endif
+constexpr int PI_MEM_OF[PI_D] = PI_MEM_OF_INIT;
+
+// Which dimension-bit of the partial-product index a corner number selects, in USER dimensions.
 // 4D/6D: bit d of corner c <-> dimension d (:607, :1035).  2D is written out with
 // dimension 1 toggling fastest (:201-209), i.e. the two bits are swapped.
 __device__ __forceinline__ constexpr int pi_corner_mask(int c) {
@@ -112,22 +135,32 @@ __device__ __forceinline__ constexpr int pi_corner_mask(int c) {
     return c;
 #endif
 }
+// The same corner as a mask over MEMORY dimensions (bit k <-> memory dimension k).
+__device__ __forceinline__ constexpr int pi_mem_mask(int user_mask) {
+    int m = 0;
+    for (int d = 0; d < PI_D; ++d) m |= ((user_mask >> d) & 1) << PI_MEM_OF[d];
+    return m;
+}
 __device__ __forceinline__ constexpr int pi_corner_offset(int c) {
-    int m = pi_corner_mask(c), off = 0;
-    for (int d = 0; d < PI_D; ++d) off += ((m >> d) & 1) * PI_GRID.stride[d];
+    int m = pi_mem_mask(pi_corner_mask(c)), off = 0;
+    for (int k = 0; k < PI_D; ++k) off += ((m >> k) & 1) * PI_GRID.stride[k];
     return off;
 }
 
-// Call the plugin with the arity the reference documents for each D (:11-15, :456-460, :869-874).
-__device__ __forceinline__ void pi_dynamics(const float (&s)[PI_D], float a, float (&ns)[PI_D],
+// Call the plugin with the arity the reference documents for each D (:11-15, :456-460, :869-874).  `sm` / `nm` hold
+// the state and its successor in MEMORY order; the plugin sees its own (the user's) order — compile-time indices, i.e.
+// register renaming.
+#define PI_U(v, d) v[PI_MEM_OF[d]]
+__device__ __forceinline__ void pi_dynamics(const float (&sm)[PI_D], float a, float (&nm)[PI_D],
                                             float* reward, bool* done) {
 #if PI_D == 2
-    step_dynamics(s[0], s[1], a, &ns[0], &ns[1], reward, done);
+    step_dynamics(PI_U(sm, 0), PI_U(sm, 1), a, &PI_U(nm, 0), &PI_U(nm, 1), reward, done);
 #elif PI_D == 4
-    step_dynamics(s[0], s[1], s[2], s[3], a, &ns[0], &ns[1], &ns[2], &ns[3], reward, done);
+    step_dynamics(PI_U(sm, 0), PI_U(sm, 1), PI_U(sm, 2), PI_U(sm, 3), a,
+                  &PI_U(nm, 0), &PI_U(nm, 1), &PI_U(nm, 2), &PI_U(nm, 3), reward, done);
 #elif PI_D == 6
-    step_dynamics(s[0], s[1], s[2], s[3], s[4], s[5], a,
-                  &ns[0], &ns[1], &ns[2], &ns[3], &ns[4], &ns[5], reward, done);
+    step_dynamics(PI_U(sm, 0), PI_U(sm, 1), PI_U(sm, 2), PI_U(sm, 3), PI_U(sm, 4), PI_U(sm, 5), a,
+                  &PI_U(nm, 0), &PI_U(nm, 1), &PI_U(nm, 2), &PI_U(nm, 3), &PI_U(nm, 4), &PI_U(nm, 5), reward, done);
 #else
 #error "PI_D must be 2, 4 or 6"
 #endif
@@ -262,15 +295,16 @@ __device__ __forceinline__ void pi_locate(const float (&ns)[PI_D], unsigned int&
 // The 2^D corner weights from the fractional offsets.  The reference multiplies
 // 1.0f * a_0 * a_1 * ... left to right for every corner; sharing the common prefixes is the
 // same sequence of roundings.  w[] is indexed by the partial-product mask (bit d <-> dim d).
+// `fr` is in MEMORY order; the products run over the USER's dimensions in ascending order.
 __device__ __forceinline__ void pi_corner_weights(const float (&fr)[PI_D], float (&w)[PI_C]) {
-    w[0] = 1.0f - fr[0];
-    w[1] = fr[0];
+    w[0] = 1.0f - PI_U(fr, 0);
+    w[1] = PI_U(fr, 0);
 #pragma unroll
     for (int k = 1; k < PI_D; ++k) {
-        const float om = 1.0f - fr[k];
+        const float om = 1.0f - PI_U(fr, k);
 #pragma unroll
         for (int m = (1 << k) - 1; m >= 0; --m) {
-            w[m + (1 << k)] = w[m] * fr[k];
+            w[m + (1 << k)] = w[m] * PI_U(fr, k);
             w[m] = w[m] * om;
         }
     }
@@ -310,8 +344,9 @@ __device__ __forceinline__ float pi_combine_corners(const PiPair (&vp)[PI_NPAIR]
     float e = 0.0f;
 #pragma unroll
     for (int c = 0; c < PI_C; ++c) {
-        const int mask = pi_corner_mask(c);
-        const float v = (mask & kLast) ? vp[mask & (kLast - 1)].y : vp[mask & (kLast - 1)].x;
+        const int mask = pi_corner_mask(c);               // user dimensions: the weight and the order of the chain
+        const int mm = pi_mem_mask(mask);                 // memory dimensions: where the value was loaded to
+        const float v = (mm & kLast) ? vp[mm & (kLast - 1)].y : vp[mm & (kLast - 1)].x;
         e = fmaf(w[mask], v, e);
     }
     return e;
@@ -1170,13 +1205,13 @@ pi_probe_step_kernel(const float* __restrict__ states, const float* __restrict__
                      unsigned char* __restrict__ done, long long m) {
     const long long k = (long long)blockIdx.x * PI_BLOCK + threadIdx.x;
     if (k >= m) return;
-    float s[PI_D], ns[PI_D], r;
+    float s[PI_D], ns[PI_D], r;                           // memory order inside, the caller's (user) order outside
     bool t;
 #pragma unroll
-    for (int d = 0; d < PI_D; ++d) s[d] = states[k * PI_D + d];
+    for (int d = 0; d < PI_D; ++d) PI_U(s, d) = states[k * PI_D + d];
     pi_dynamics(s, acts[k], ns, &r, &t);
 #pragma unroll
-    for (int d = 0; d < PI_D; ++d) next[k * PI_D + d] = ns[d];
+    for (int d = 0; d < PI_D; ++d) next[k * PI_D + d] = PI_U(ns, d);
     reward[k] = r;
     done[k] = t ? 1 : 0;
 }
@@ -1186,9 +1221,9 @@ pi_probe_interp_kernel(const float* __restrict__ pts, int* __restrict__ idxs,
                        float* __restrict__ wgts, long long m) {
     const long long k = (long long)blockIdx.x * PI_BLOCK + threadIdx.x;
     if (k >= m) return;
-    float p[PI_D], fr[PI_D], w[PI_C];
+    float p[PI_D], fr[PI_D], w[PI_C];                     // points in the user's order; indices are MEMORY-order flat indices
 #pragma unroll
-    for (int d = 0; d < PI_D; ++d) p[d] = pts[k * PI_D + d];
+    for (int d = 0; d < PI_D; ++d) PI_U(p, d) = pts[k * PI_D + d];
     unsigned int base;
     pi_locate(p, base, fr);
     pi_corner_weights(fr, w);
@@ -1216,6 +1251,6 @@ pi_probe_coords_kernel(const float* __restrict__ tab, long long s_begin, long lo
         float x[PI_D];
         pi_state_coords((unsigned int)s, lds_tab, x);
 #pragma unroll
-        for (int d = 0; d < PI_D; ++d) out[(s - s_begin) * PI_D + d] = x[d];
+        for (int d = 0; d < PI_D; ++d) out[(s - s_begin) * PI_D + d] = PI_U(x, d);      // columns in the user's order
     }
 }

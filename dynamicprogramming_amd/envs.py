@@ -252,6 +252,9 @@ class DoublePendulumSwingUpCuda(CudaPolicyIteration4D):
     reward shaping), :288-294 (config)."""
 
     DEFAULT_BINS = 15
+    # device memory order (theta1, theta2, th1_dot, th2_dot): 80^4 evaluation sweep 0.399 -> 0.372 ms on MI355X
+    # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt); big grids only (solver._ORDER_MIN_STATES)
+    MEMORY_ORDER = (0, 2, 1, 3)
     ACTIONS = np.array([-3.0, -1.5, -0.5, -0.15, -0.05, 0.0, 0.05, 0.15, 0.5, 1.5, 3.0],
                        dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=15_000, max_pi_iter=300, log_interval=500)
@@ -473,6 +476,9 @@ class DoubleCartPoleCuda(CudaPolicyIteration6D):
     (terminal mask); config gamma .999 / 10 000 / 200."""
 
     DEFAULT_BINS = 15
+    # device memory order (x, x_dot, theta1, th1_dot, th2_dot, theta2): 25^6 evaluation sweep 3.68 -> 3.29 ms
+    # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt)
+    MEMORY_ORDER = (0, 1, 2, 3, 5, 4)
     ACTIONS = np.array([-10.0, 0.0, 10.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=10_000, max_pi_iter=200, log_interval=500)
     _TH_FAIL = 20.0 * np.pi / 180.0
@@ -522,6 +528,9 @@ class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
     reward shaping), :241-245 (terminal mask); config gamma .999 / 20 000 / 300."""
 
     DEFAULT_BINS = 20
+    # device memory order (x, theta1, th1_dot, x_dot, theta2, th2_dot): 25^6 evaluation sweep 7.84 -> 7.16 ms
+    # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt)
+    MEMORY_ORDER = (0, 2, 3, 1, 4, 5)
     ACTIONS = np.array([-60.0, -30.0, -10.0, -3.0, 0.0, 3.0, 10.0, 30.0, 60.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=20_000, max_pi_iter=300, log_interval=500)
 

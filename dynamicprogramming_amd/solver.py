@@ -70,7 +70,7 @@ class HipSweepBackend:
     """Sweeps through libpi_mi355.so on one GPU.  Tensors are torch-ROCm device tensors;
     launches go on torch's current stream so torch-side ops and events order with them."""
 
-    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None):
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None, order=None):
         import torch
         if not _native.available():
             raise RuntimeError("libpi_mi355.so is not available: " + _native_reason())
@@ -79,13 +79,19 @@ class HipSweepBackend:
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None
                                    else torch.device(device).index or 0)
-        self.engine = _native.Engine(D, grid_shape, lo, hi, bins, actions, device=self.device.index)
+        self.engine = _native.Engine(D, grid_shape, lo, hi, bins, actions, device=self.device.index, order=order)
         t0 = time.perf_counter()
         self.engine.compile(dynamics_src)
         self.compile_seconds = time.perf_counter() - t0
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_memory(self, a):
+        return self.engine.to_memory(a)
+
+    def to_user(self, a):
+        return self.engine.to_user(a)
 
     @staticmethod
     def _ptr(term) -> int:
@@ -171,6 +177,15 @@ class _CudaPolicyIterationBase(abc.ABC):
     """Shared implementation; the public classes fix ``_D``."""
 
     _D: int = 0
+    # Memory order of the dimensions on the device (None: the user's order).  MEMORY_ORDER[k] = the dimension stored as
+    # memory dimension k, 0 = slowest.  Which dimensions are slow decides how far apart the corners of a successor cell
+    # lie and how long a value stays useful in an XCD's L2; the best order is a property of the env's dynamics
+    # (tools/dim_order_sweep.py measures it: 7-11 % on the evaluation sweeps of the big BASELINE grids).  Applied to
+    # grids of at least _ORDER_MIN_STATES states; PI_MI355_ORDER=user | "0,2,1,3" overrides.  Host-side arrays
+    # (value_function, policy, states_space, archives, checkpoints) are always in the user's order; the device
+    # tensors (d_value_function, d_policy, d_terminal_mask) are in memory order.
+    MEMORY_ORDER = None
+    _ORDER_MIN_STATES = 1 << 22
     # Sweep backend class.  Private: the product has exactly one (the HIP backend); the CPU test-suite
     # swaps a checker in here to exercise the host logic without a GPU (tests/helpers.py).
     _sweep_backend_cls = None
@@ -211,6 +226,7 @@ class _CudaPolicyIterationBase(abc.ABC):
                       "sweeps_per_iter": [], "eval_seconds": 0.0, "improve_seconds": 0.0}
 
         self._precompute_grid_metadata()
+        self._order = self._choose_memory_order()
         self._allocate_tensors_and_compile()
 
     # ── grid ────────────────────────────────────────────────────────────────────────
@@ -226,6 +242,28 @@ class _CudaPolicyIterationBase(abc.ABC):
     @states_space.setter
     def states_space(self, value) -> None:
         self._states_space = value
+
+    def _choose_memory_order(self):
+        import os
+        env = os.environ.get("PI_MI355_ORDER", "").strip().lower()
+        if env in ("user", "identity", "none"):
+            return None
+        if env:
+            order = tuple(int(v) for v in env.split(","))
+        elif self.MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES:
+            order = tuple(self.MEMORY_ORDER)
+        else:
+            return None
+        if sorted(order) != list(range(self._D)):
+            raise ValueError(f"memory order {order} is not a permutation of the {self._D} dimensions")
+        return None if order == tuple(range(self._D)) else order
+
+    def _to_memory(self, a):
+        """Whole-grid array in the user's order -> the device's memory order (identity without MEMORY_ORDER)."""
+        return a if self._order is None else self._backend.to_memory(a)
+
+    def _to_user(self, a):
+        return a if self._order is None else self._backend.to_user(a)
 
     def _precompute_grid_metadata(self) -> None:
         # Same quantities as :95-109 / :497-514 / :912-937, from the bin tables instead of
@@ -266,9 +304,12 @@ class _CudaPolicyIterationBase(abc.ABC):
         import torch
         logger.info("Allocating device tensors and compiling gfx950 kernels...")
         factory = self._sweep_backend_cls or HipSweepBackend
+        kw = {} if self._order is None else {"order": self._order}
         self._backend = factory(self._D, self.grid_shape, self.bounds_low, self.bounds_high,
                                 self._bins, self.action_space, self._dynamics_cuda_src(),
-                                device=self._device_arg)
+                                device=self._device_arg, **kw)
+        if self._order is not None:
+            logger.info(f"memory order of the dimensions: {[self._bin_keys[d] for d in self._order]}")
         dev = self._backend.device
         self._init_sharding()
 
@@ -287,7 +328,8 @@ class _CudaPolicyIterationBase(abc.ABC):
             terminal_mask, terminal_value = None, 0.0
         self.d_terminal_mask = torch.zeros(n_pad, dtype=torch.uint8, device=dev)
         if terminal_mask is not None and terminal_mask.any():
-            self.d_terminal_mask[:n] = torch.from_numpy(terminal_mask.view(np.uint8)).to(dev)
+            self.d_terminal_mask[:n] = torch.from_numpy(
+                np.ascontiguousarray(self._to_memory(terminal_mask.view(np.uint8)))).to(dev)
             self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
             logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
         self.d_new_value_function.copy_(self.d_value_function)
@@ -324,7 +366,8 @@ class _CudaPolicyIterationBase(abc.ABC):
         cells a non-zero starting value (the crane runner does this by reaching into cupy,
         runners/overhead_crane_cuda.py:193-206)."""
         import torch
-        m = torch.from_numpy(np.ascontiguousarray(mask, dtype=bool)).to(self.d_value_function.device)
+        m = torch.from_numpy(np.ascontiguousarray(self._to_memory(np.ascontiguousarray(mask, dtype=bool)))).to(
+            self.d_value_function.device)
         self.d_value_function[: self.n_states][m] = float(value)
         self.d_new_value_function[: self.n_states][m] = float(value)
 
@@ -513,8 +556,9 @@ class _CudaPolicyIterationBase(abc.ABC):
         if self._rank == 0:
             filepath.parent.mkdir(parents=True, exist_ok=True)
             tmp = filepath.with_name(filepath.name + f".tmp{os.getpid()}.npz")
-            np.savez(tmp, value_function=self.d_value_function[:n].cpu().numpy(),
-                     policy=self.d_policy[:n].cpu().numpy(), grid_shape=self.grid_shape,
+            np.savez(tmp, value_function=np.ascontiguousarray(self._to_user(self.d_value_function[:n].cpu().numpy())),
+                     policy=np.ascontiguousarray(self._to_user(self.d_policy[:n].cpu().numpy())),
+                     grid_shape=self.grid_shape,
                      action_space=self.action_space,
                      eval_sweeps=np.int64(self.stats["eval_sweeps"]),
                      improve_sweeps=np.int64(self.stats["improve_sweeps"]),
@@ -531,9 +575,9 @@ class _CudaPolicyIterationBase(abc.ABC):
                 and np.array_equal(data["action_space"], self.action_space)):
             raise ValueError("checkpoint was written for a different grid or action set")
         n, dev = self.n_states, self.d_value_function.device
-        self.d_value_function[:n].copy_(torch.from_numpy(data["value_function"]).to(dev))
+        self.d_value_function[:n].copy_(torch.from_numpy(np.ascontiguousarray(self._to_memory(data["value_function"]))).to(dev))
         self.d_new_value_function.copy_(self.d_value_function)
-        self.d_policy[:n].copy_(torch.from_numpy(data["policy"]).to(dev))
+        self.d_policy[:n].copy_(torch.from_numpy(np.ascontiguousarray(self._to_memory(data["policy"]))).to(dev))
         for key in ("eval_sweeps", "improve_sweeps", "pi_iterations"):
             self.stats[key] = int(data[key])
         if "sweeps_per_iter" in data:
@@ -546,8 +590,8 @@ class _CudaPolicyIterationBase(abc.ABC):
             self._comm.all_gather(self, self.d_policy)
             self._comm.all_gather(self, self.d_value_function)    # halo mode: V is only local + halos
         n = self.n_states
-        self.value_function = self.d_value_function[:n].cpu().numpy()
-        self.policy = self.d_policy[:n].cpu().numpy()
+        self.value_function = np.ascontiguousarray(self._to_user(self.d_value_function[:n].cpu().numpy()))
+        self.policy = np.ascontiguousarray(self._to_user(self.d_policy[:n].cpu().numpy()))
         for attr in ["d_terminal_mask", "_term_arg", "d_value_function", "d_new_value_function", "d_policy",
                      "_d_delta", "_d_changed"]:
             if hasattr(self, attr):

@@ -326,7 +326,17 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
 
 /* Tuning: 0 = chunks per workgroup of the evaluation sweeps, 1 = of the improvement / value sweeps
  * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of
- * small grids in the LDS-resident kernel (0 | 1).  Results do not depend on any of them. */
+ * small grids in the LDS-resident kernel (0 | 1), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
+ * digit k (base 8) of the value is the dimension — numbered as in pi_create and in step_dynamics' arguments —
+ * that is stored as memory dimension k, 0 = slowest; e.g. 03120 (octal) = order (0, 2, 1, 3).  From then on
+ * EVERY flat state index of this ABI (s_begin / s_end, the entries of V, policy and the mask, the indices the
+ * interpolation probe returns) refers to that order: index = sum_k i_{order[k]} * stride_k with row-major
+ * strides over the permuted shape.  The reference has one order, the meshgrid's (:84-87); which dimensions
+ * are slow decides how far apart in memory the 2^D corners of a successor cell lie and how long a value
+ * stays useful in an XCD's L2 — the best order beats the user's by 7-11 % on the evaluation sweeps of the
+ * big BASELINE grids (tools/dim_order_sweep.py).  The order-sensitive arithmetic (corner weights as products
+ * over the dimensions, the fmaf chain over the corners, :580-614, :616-649) stays in the caller's dimension
+ * order, so results do not depend on the memory order, bit for bit; neither do they depend on options 0-3. */
 int pi_set_option(pi_handle* h, int what, int64_t value);
 
 /* Introspection: 0 n_states, 1 n_actions, 2 D, 3 chunks per workgroup (evaluation), 4 VGPRs of the
@@ -335,7 +345,7 @@ int pi_set_option(pi_handle* h, int what, int64_t value);
  * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
  * batch kernel (0: grid too big for it), 14 that kernel enabled, 15 checked kernels (pi_debug_report),
  * 16 live states listed by pi_prepare_mask (0: no list in use), 17 entries of the per-evaluation list of
- * pi_eval_begin (0: none),
+ * pi_eval_begin (0: none), 18 the memory order as set with pi_set_option 4 (octal digits, identity by default),
  * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */
 int64_t pi_info(pi_handle* h, int what);
 

@@ -94,10 +94,13 @@ class OracleSweepBackend:
     sharding over gloo ranks).  Lives under tests/ so the product can never pick it up; tests
     install it with ``with_checker_backend``."""
 
-    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None):
+    def __init__(self, D, grid_shape, lo, hi, bins, actions, dynamics_src, device=None, order=None):
         import torch
         self.torch = torch
         self.device = torch.device("cpu")
+        # memory order of the dimensions (solver.MEMORY_ORDER): the "device" arrays the solver hands over are in that
+        # order; the checker itself works in the user's order, whole grids only
+        self.order = None if order is None else tuple(int(d) for d in order)
         self.lib = oracle.build(int(D), dynamics_src)
         self.lo, self.hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
         self.shape = np.asarray(grid_shape, np.int32)
@@ -110,20 +113,45 @@ class OracleSweepBackend:
         self.n = len(self.states)
         self.calls = {"eval": 0, "improve": 0}
 
+    def to_memory(self, a):
+        if self.order is None:
+            return a
+        b = a.reshape([int(g) for g in self.shape])
+        b = b.permute(*self.order).contiguous() if hasattr(b, "permute") else np.ascontiguousarray(b.transpose(self.order))
+        return b.reshape(-1)
+
+    def to_user(self, a):
+        if self.order is None:
+            return a
+        inv = [self.order.index(d) for d in range(len(self.order))]
+        b = a.reshape([int(self.shape[d]) for d in self.order])
+        b = b.permute(*inv).contiguous() if hasattr(b, "permute") else np.ascontiguousarray(b.transpose(inv))
+        return b.reshape(-1)
+
+    def _u(self, t):
+        """numpy view (user's order) of a whole-grid device tensor; a copy when the memory order differs."""
+        a = t.numpy()[: self.n]
+        return a if self.order is None else self.to_user(a)
+
+    def _whole(self, s_begin, s_end):
+        assert self.order is None or (s_begin == 0 and s_end == self.n), "memory orders: whole-grid sweeps only"
+
     def _mask(self, term):
         """The solver passes None for a grid without terminal states (the product then streams no mask)."""
-        return np.zeros(self.n, dtype=np.uint8) if term is None else term.numpy()[: self.n]
+        return np.zeros(self.n, dtype=np.uint8) if term is None else self._u(term)
 
     def eval_sweeps(self, Va, Vb, policy, term, s_begin, s_end, gamma, n_sweeps, d_delta,
                     rebuild=True):
         n = self.n
+        self._whole(s_begin, s_end)
         for i in range(n_sweeps):
             src, dst = (Vb, Va) if (i & 1) else (Va, Vb)
-            out = dst.numpy()
-            _, delta = self.lib.eval_sweep(self.states, self.actions, policy.numpy()[:n],
-                                           src.numpy()[:n], self._mask(term), self.lo, self.hi,
+            out = np.ascontiguousarray(self._u(dst))
+            _, delta = self.lib.eval_sweep(self.states, self.actions, self._u(policy),
+                                           self._u(src), self._mask(term), self.lo, self.hi,
                                            self.shape, self.strides, gamma, s_begin, s_end,
-                                           out=out[:n])
+                                           out=out)
+            dst.numpy()[:n] = self.to_memory(out)
             self.calls["eval"] += 1
             if d_delta is not None and i == n_sweeps - 1:
                 d_delta[0] = delta
@@ -157,20 +185,30 @@ class OracleSweepBackend:
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed):
         n = self.n
-        new_pol, changed = self.lib.improve_sweep(self.states, self.actions, policy.numpy()[:n],
-                                                  V.numpy()[:n], self._mask(term), self.lo, self.hi,
+        self._whole(s_begin, s_end)
+        new_pol, changed = self.lib.improve_sweep(self.states, self.actions, self._u(policy),
+                                                  self._u(V), self._mask(term), self.lo, self.hi,
                                                   self.shape, self.strides, gamma, s_begin, s_end)
-        policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+        if self.order is None:
+            policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+        else:
+            policy.numpy()[:n] = self.to_memory(new_pol)
         self.calls["improve"] += 1
         if d_changed is not None:
             d_changed[0] = changed
 
     def value_sweep(self, V, Vnew, policy, term, s_begin, s_end, gamma, d_delta, d_changed):
         n = self.n
+        self._whole(s_begin, s_end)
+        out = np.ascontiguousarray(self._u(Vnew))
         _, new_pol, delta, changed = self.lib.value_sweep(
-            self.states, self.actions, policy.numpy()[:n], V.numpy()[:n], self._mask(term), self.lo,
-            self.hi, self.shape, self.strides, gamma, s_begin, s_end, out=Vnew.numpy()[:n])
-        policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+            self.states, self.actions, self._u(policy), self._u(V), self._mask(term), self.lo,
+            self.hi, self.shape, self.strides, gamma, s_begin, s_end, out=out)
+        Vnew.numpy()[:n] = self.to_memory(out)
+        if self.order is None:
+            policy.numpy()[:n][s_begin:s_end] = new_pol[s_begin:s_end]
+        else:
+            policy.numpy()[:n] = self.to_memory(new_pol)
         if d_delta is not None:
             d_delta[0] = delta
         if d_changed is not None:

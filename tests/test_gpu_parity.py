@@ -941,3 +941,159 @@ def test_rccl_entry_points_world_1(cuda_device):
     with pytest.raises(_native.NativeError, match="no communicator"):
         eng.allgather_V(B.data_ptr(), n)
     eng.close()
+
+
+# ── memory order of the dimensions (pi_set_option 4 / solver.MEMORY_ORDER) ───────────────────────────────
+ORDER_CASES = [("pendulum", (23, 17), (1, 0)),
+               ("cartpole_swingup", (9, 7, 11, 5), (0, 2, 1, 3)),
+               ("double_pendulum_swingup", (8, 9, 7, 10), (2, 0, 3, 1)),
+               ("overhead_crane", (7, 6, 8, 5), (3, 2, 1, 0)),
+               ("double_cartpole", (5, 4, 6, 4, 5, 4), (0, 1, 2, 3, 5, 4)),
+               ("double_cartpole_swingup", (4, 5, 4, 3, 5, 4), (0, 2, 3, 1, 4, 5))]
+
+
+@pytest.mark.parametrize("name,shape,order", ORDER_CASES)
+def test_memory_order_sweeps_are_bit_exact(name, shape, order, cuda_device):
+    """An engine whose grid lives in another memory order (which dimensions are slow; lanes run along order[-1]) gives
+    the oracle's bits: evaluation sweeps (whole grid, ragged ranges of MEMORY-order indices, a batch), the improvement
+    and the value sweep, the dynamics probe (user-order I/O) and the interpolation probe (weights in the reference's
+    corner order; indices are memory-order flat indices).  Only where a state lives changes."""
+    torch = _torch()
+    cls = envs.ENVS[name]
+    D = cls._D
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    eng = _native.Engine(D, [len(b) for b in bins], [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0, order=order)
+    eng.compile(envs.dynamics_source(name))
+    assert eng.order == tuple(order)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    states = oracle.states_from_bins(bins)
+    term, tval = H.terminal_mask(name, states)
+    n = len(states)
+    rng = np.random.default_rng(31)
+    V = (rng.standard_normal(n) * 3.0).astype(np.float32)
+    V[term] = np.float32(tval)
+    pol = rng.integers(0, len(acts), size=n).astype(np.int32)
+    pol[term] = 0
+    gamma = float(np.float32(0.97))
+    chk = H.oracle_for(name)
+    tm = lambda a: np.ascontiguousarray(eng.to_memory(np.ascontiguousarray(a)))     # noqa: E731
+    d_V, d_pol, d_term = _dev(tm(V), cuda_device), _dev(tm(pol), cuda_device), _dev(tm(term.astype(np.uint8)), cuda_device)
+    tptr = d_term.data_ptr() if term.any() else 0
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    # whole-grid evaluation sweep + residual
+    d_Vn = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), tptr, 0, n, gamma, d_delta.data_ptr())
+    torch.cuda.synchronize()
+    o_V, o_delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(eng.to_user(d_Vn.cpu().numpy()), o_V, f"{name} {order} V'")
+    assert np.float32(d_delta.item()) == np.float32(o_delta)
+    # a ragged range of memory-order indices: exactly those states are written
+    a, b = n // 5 + 3, n - n // 7 - 1
+    d_Vr = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vr.data_ptr(), d_pol.data_ptr(), tptr, a, b, gamma, 0)
+    torch.cuda.synchronize()
+    got = d_Vr.cpu().numpy()
+    assert np.isnan(got[:a]).all() and np.isnan(got[b:]).all()
+    H.assert_bits_equal(got[a:b], tm(o_V)[a:b], f"{name} {order} ragged range")
+    # a 4-sweep batch (graph / eager / LDS-resident path, whatever the grid takes)
+    Va, Vb = d_V.clone(), torch.zeros_like(d_V)
+    eng.eval_sweeps(Va.data_ptr(), Vb.data_ptr(), d_pol.data_ptr(), tptr, 0, n, gamma, 4, d_delta.data_ptr())
+    torch.cuda.synchronize()
+    ref = V
+    for _ in range(4):
+        ref, o_delta = chk.eval_sweep(states, acts, pol, ref, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(eng.to_user(Va.cpu().numpy()), ref, f"{name} {order} batch of 4")
+    assert np.float32(d_delta.item()) == np.float32(o_delta)
+    # improvement and value sweep
+    d_p2, d_ch = d_pol.clone(), torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), tptr, 0, n, gamma, d_ch.data_ptr())
+    torch.cuda.synchronize()
+    o_pol, o_changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    assert np.array_equal(eng.to_user(d_p2.cpu().numpy()), o_pol) and int(d_ch.item()) == o_changed
+    d_p3, d_Vv = d_pol.clone(), torch.zeros_like(d_V)
+    eng.value_sweep(d_V.data_ptr(), d_Vv.data_ptr(), d_p3.data_ptr(), tptr, 0, n, gamma, d_delta.data_ptr(), d_ch.data_ptr())
+    torch.cuda.synchronize()
+    v_V, v_pol, v_delta, v_changed = chk.value_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(eng.to_user(d_Vv.cpu().numpy()), v_V, f"{name} {order} value sweep V'")
+    assert np.array_equal(eng.to_user(d_p3.cpu().numpy()), v_pol)
+    assert np.float32(d_delta.item()) == np.float32(v_delta) and int(d_ch.item()) == v_changed
+    # probes: dynamics in the user's argument order; interpolation weights in the reference's corner order
+    pts = H.sample_states(rng, bins, 600)
+    act = rng.choice(acts, size=len(pts)).astype(np.float32)
+    m = len(pts)
+    d_next = torch.empty((m, D), dtype=torch.float32, device=cuda_device)
+    d_rew = torch.empty(m, dtype=torch.float32, device=cuda_device)
+    d_done = torch.empty(m, dtype=torch.uint8, device=cuda_device)
+    d_pts, d_act = _dev(pts, cuda_device), _dev(act, cuda_device)      # kept alive until the probes have run
+    eng.probe_step(d_pts.data_ptr(), d_act.data_ptr(), d_next.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), m)
+    d_idx = torch.empty((m, 1 << D), dtype=torch.int32, device=cuda_device)
+    d_w = torch.empty((m, 1 << D), dtype=torch.float32, device=cuda_device)
+    eng.probe_interp(d_pts.data_ptr(), d_idx.data_ptr(), d_w.data_ptr(), m)
+    torch.cuda.synchronize()
+    o_next, o_rew, o_done = chk.step(pts, act)
+    H.assert_bits_equal(d_next.cpu().numpy(), o_next, "probe: next state")
+    H.assert_bits_equal(d_rew.cpu().numpy(), o_rew, "probe: reward")
+    assert np.array_equal(d_done.cpu().numpy().astype(bool), o_done)
+    o_idx, o_w = chk.interp(pts, lo, hi, gshape, strides)
+    H.assert_bits_equal(d_w.cpu().numpy(), o_w, "probe: weights")
+    mem_of_user_flat = np.empty(n, dtype=np.int64)                     # user flat index -> memory flat index
+    mem_of_user_flat[eng.to_memory(np.arange(n, dtype=np.int64))] = np.arange(n, dtype=np.int64)
+    assert np.array_equal(d_idx.cpu().numpy(), mem_of_user_flat[o_idx])
+    # the coordinate probe: columns in the user's order, rows in memory order
+    d_xy = torch.empty((n, D), dtype=torch.float32, device=cuda_device)
+    eng.probe_coords(0, n, d_xy.data_ptr(), 2)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_xy.cpu().numpy(), states[eng.to_memory(np.arange(n, dtype=np.int64))])
+    eng.close()
+
+
+@pytest.mark.parametrize("name,shape,order,world", [("double_pendulum_swingup", (14, 9, 11, 8), (0, 2, 1, 3), 1),
+                                                     ("double_pendulum_swingup", (14, 9, 11, 8), (0, 2, 1, 3), 3),
+                                                     ("cartpole_swingup", (18, 7, 9, 8), (1, 0, 3, 2), 2),
+                                                     ("double_cartpole", (6, 4, 5, 4, 5, 4), (0, 1, 2, 3, 5, 4), 2),
+                                                     ("pendulum", (41, 13), (1, 0), 1)])
+def test_memory_order_full_runs_equal_the_oracle(name, shape, order, world, cuda_device, monkeypatch):
+    """run() of a solver whose device tensors are in another memory order (PI_MI355_ORDER), on one rank and sharded
+    over logical ranks (slabs of the SLOWEST MEMORY dimension; halo exchange through the in-process transport):
+    value_function, policy and the sweep count of every evaluation equal the oracle's run in the user's order."""
+    import threading
+    import uuid
+    from dynamicprogramming_amd import transport as T
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_ORDER", ",".join(map(str, order)))
+    monkeypatch.setenv("PI_MI355_EXCHANGE", "halo")
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 3, "max_eval_iter": 60}
+    cfg = envs.CudaPIConfig(**cfg_kw)
+    tables = H.env_bins(name, shape)
+    lo, hi, gshape, strides = oracle.grid_metadata(tables)
+    states = oracle.states_from_bins(tables)
+    term, tval = H.terminal_mask(name, states)
+    ref = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, gamma=cfg.gamma, theta=cfg.theta,
+                                 max_eval_iter=cfg.max_eval_iter, max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
+    group = f"order-{uuid.uuid4().hex}"
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+                kw = {"transport": T.NativeTransport.local(r, world, group)} if world > 1 else {}
+                s = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device, **kw)
+                assert s._order == tuple(order) and s._backend.engine.order == tuple(order)
+                s.run()
+                out[r] = (s.value_function, s.policy, list(s.stats["sweeps_per_iter"]))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(world):
+        V, pol, sweeps = out[r]
+        H.assert_bits_equal(V, ref["value_function"], f"rank {r} V")
+        assert np.array_equal(pol, ref["policy"]) and sweeps == list(ref["sweeps_per_iter"])

@@ -230,3 +230,67 @@ def test_runner_loads_an_existing_archive_without_a_gpu(tmp_path, capsys):
                                  d["corner_bits"]))
     assert d["action_space"].min() <= a <= d["action_space"].max()
     assert _cli.main("mountain_car", "unused.npz", ["--random"]) is None      # no training, like the reference
+
+
+# ── memory order of the dimensions (solver.MEMORY_ORDER / PI_MI355_ORDER) ───────────────────────────────
+@pytest.mark.parametrize("name,shape,order", [("cartpole_swingup", (7, 5, 9, 6), (0, 2, 1, 3)),
+                                               ("double_pendulum_swingup", (6, 5, 7, 4), (3, 1, 0, 2)),
+                                               ("pendulum", (17, 13), (1, 0)),
+                                               ("double_cartpole", (3, 4, 3, 4, 3, 5), (0, 1, 2, 3, 5, 4))])
+def test_memory_order_moves_states_not_results(name, shape, order, tmp_path, monkeypatch):
+    """With a memory order the device tensors hold the grid transposed; everything the host sees — value_function,
+    policy, checkpoints, archives — stays in the user's order and every number stays the same: run() with and without
+    the order agree bit for bit (V, policy, sweep counts), the mask on the "device" is the transposed mask, a mid-run
+    checkpoint written with the order is read back without it (and vice versa)."""
+    cfg = CudaPIConfig(**{**envs.ENVS[name].CONFIG, "max_pi_iter": 3, "max_eval_iter": 80})
+    plain = _solver(name, shape, cfg)
+    cls = type(plain)
+    ordered_cls = type(cls.__name__ + "Ordered", (cls,), {"MEMORY_ORDER": order, "_ORDER_MIN_STATES": 0})
+    s = ordered_cls(H.env_bins_space(name, shape), envs.ENVS[name].ACTIONS, cfg)
+    assert s._order == order and plain._order is None
+    n = s.n_states
+    mask_user, _ = H.terminal_mask(name, s.states_space)
+    got = s.d_terminal_mask.numpy()[:n].astype(bool)
+    want = np.ascontiguousarray(mask_user.reshape(shape).transpose(order)).reshape(-1)
+    assert np.array_equal(got, want)
+    assert np.array_equal(s._to_user(got), mask_user) and np.array_equal(s._to_memory(mask_user), got)
+    # two evaluations + an improvement, then checkpoints cross over
+    for sol in (s, plain):
+        sol.policy_evaluation()
+        sol.policy_improvement()
+    s.save_checkpoint(tmp_path / "ordered")
+    plain.save_checkpoint(tmp_path / "plain")
+    a, b = np.load(tmp_path / "ordered.npz"), np.load(tmp_path / "plain.npz")
+    H.assert_bits_equal(a["value_function"], b["value_function"], "checkpoint V (user order)")
+    assert np.array_equal(a["policy"], b["policy"])
+    s2 = ordered_cls(H.env_bins_space(name, shape), envs.ENVS[name].ACTIONS, cfg)
+    s2.load_checkpoint(tmp_path / "plain")
+    p2 = _solver(name, shape, cfg)
+    p2.load_checkpoint(tmp_path / "ordered")
+    for sol in (s2, p2):
+        sol.run()
+    plain_full = _solver(name, shape, cfg)
+    plain_full.policy_evaluation()
+    plain_full.policy_improvement()
+    plain_full.run()
+    for sol in (s2, p2):
+        H.assert_bits_equal(sol.value_function, plain_full.value_function, "V after resume")
+        assert np.array_equal(sol.policy, plain_full.policy)
+    # PI_MI355_ORDER overrides the class: "user" switches it off, a list forces one
+    monkeypatch.setenv("PI_MI355_ORDER", "user")
+    assert ordered_cls(H.env_bins_space(name, shape), envs.ENVS[name].ACTIONS, cfg)._order is None
+    monkeypatch.setenv("PI_MI355_ORDER", ",".join(map(str, order)))
+    assert _solver(name, shape, cfg)._order == order
+    monkeypatch.setenv("PI_MI355_ORDER", "0,0,1,2")
+    with pytest.raises(ValueError, match="permutation"):
+        _solver(name, shape, cfg)
+
+
+def test_memory_order_applies_to_big_grids_only():
+    """The class default is taken from a threshold on: small grids (all of this suite's) stay in the user's order."""
+    cls = envs.ENVS["double_pendulum_swingup"]
+    assert cls.MEMORY_ORDER is not None and sorted(cls.MEMORY_ORDER) == [0, 1, 2, 3]
+    assert _solver("double_pendulum_swingup", (6, 5, 7, 4))._order is None
+    for name, c in envs.ENVS.items():
+        if c.MEMORY_ORDER is not None:
+            assert sorted(c.MEMORY_ORDER) == list(range(c._D)), name

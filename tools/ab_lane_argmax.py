@@ -91,8 +91,9 @@ def main():
     mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
     assert hip.hipModuleLoad(ctypes.byref(mod), str(tmp / "ab.hsaco").encode()) == 0
     assert hip.hipModuleGetFunction(ctypes.byref(fn), mod, b"ab_improve_lanes_kernel") == 0
+    user_tables = [np.asarray(b, np.float32) for b in cls.bins_space(bins).values()]
     d_tab = torch.from_numpy(np.concatenate([cls.ACTIONS.astype(np.float32)] +
-                                            [np.asarray(b, np.float32) for b in cls.bins_space(bins).values()])).cuda()
+                                            [user_tables[d] for d in eng.order])).cuda()        # the engine's memory order
     pol_a = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     pol_b = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     ch_a = torch.zeros(1, dtype=torch.int32, device="cuda:0")

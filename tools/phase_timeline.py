@@ -292,6 +292,60 @@ pt_eval_persistent_kernel(const float* __restrict__ V, float* __restrict__ Vn, c
                unsigned int* __restrict__ trace, unsigned int* __restrict__ trace_count, unsigned int trace_cap, int it0) {
     pt_eval_body<1>(V, Vn, policy, tab, s_begin, s_end, gamma, cpw, trace, trace_count, trace_cap, it0);
 }
+
+// ---- experiment: one thread sweeps PT_G states that differ only in dimension PT_GDIM (tools/phase_timeline.py) ----
+// Everything in step_dynamics that does not depend on x[PT_GDIM] (nor on the action) is loop-invariant and the compiler
+// hoists it out of the loop over the PT_G states, as it does over the action loop of the improvement sweep.  A workgroup
+// takes a "tile": PI_BLOCK_EVAL consecutive states inside one run of the dimensions behind PT_GDIM, times PT_G
+// consecutive indices of PT_GDIM; lanes stay adjacent in memory, every policy load and V' store stays coalesced.
+#ifndef PT_G
+#define PT_G 4
+#endif
+#ifndef PT_GDIM
+#define PT_GDIM 1
+#endif
+extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL) __attribute__((amdgpu_num_sgpr(80)))
+pt_eval_gloop_kernel(const float* __restrict__ V, float* __restrict__ Vn, const int* __restrict__ policy,
+               const float* __restrict__ tab, long long s_begin, long long s_end, float gamma, int cpw,
+               unsigned int* __restrict__ trace, unsigned int* __restrict__ trace_count, unsigned int trace_cap, int it0) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    constexpr unsigned int kRun = (unsigned int)PI_GRID.stride[PT_GDIM];               // states behind PT_GDIM
+    constexpr bool kFits = kRun % PI_BLOCK_EVAL == 0 && PI_GRID.g[PT_GDIM] % PT_G == 0;   // else: not launched
+    constexpr unsigned int kPerRun = kFits ? kRun / PI_BLOCK_EVAL : 1, kBlocks = kFits ? PI_GRID.g[PT_GDIM] / PT_G : 1;
+    if (!kFits) return;
+    const unsigned int tiles = (unsigned int)(PI_GRID.n / ((long long)PI_BLOCK_EVAL * PT_G));
+    const unsigned int span = gridDim.x / PI_NXCD;
+    const unsigned int T = (blockIdx.x % PI_NXCD) * span + blockIdx.x / PI_NXCD;
+    if (T >= tiles) return;
+    const unsigned int outer = T / (kBlocks * kPerRun), gb = (T / kPerRun) % kBlocks, r = T % kPerRun;
+    const unsigned int tid = threadIdx.x;
+    // first state of the lane: index `outer` over the dimensions in front of PT_GDIM, gb * PT_G along it, r-th piece of the run
+    const unsigned int s0 = (outer * (unsigned int)PI_GRID.g[PT_GDIM] + gb * PT_G) * kRun + r * PI_BLOCK_EVAL + tid;
+    int act[PT_G];
+#pragma unroll
+    for (int k = 0; k < PT_G; ++k) act[k] = __builtin_nontemporal_load(policy + s0 + k * kRun);
+    pi_stage_table<PI_BLOCK_EVAL>(tab, lds_tab);
+    __syncthreads();
+    float x[PI_D];
+    pi_state_coords(s0, lds_tab, x);
+    const int i_g = (int)(gb * PT_G);
+#pragma unroll
+    for (int k = 0; k < PT_G; ++k) {
+        float ns[PI_D], reward;
+        x[PT_GDIM] = lds_tab[PI_GRID.bins_off[PT_GDIM] + i_g + k];
+        const float a = lds_tab[PI_TAB_ACT + act[k]];
+        bool done;
+        pi_dynamics(x, a, ns, &reward, &done);
+        float e = 0.0f;
+        if (!done) {
+            unsigned int base;
+            float fr[PI_D];
+            pi_locate(ns, base, fr);
+            e = pi_interpolate(V, base, fr);
+        }
+        Vn[s0 + k * kRun] = reward + gamma * e;
+    }
+}
 '''
 
 PHASES = ["A>B wait for inputs", "B>C dynamics + cell search", "C>D issue corner loads", "D>E wait for corner values",
@@ -508,6 +562,7 @@ def main():
     ap.add_argument("--variants", default="", help="prologue variants of the copy, e.g. R1P0,R0P32,R1P32 (R: table loads before "
                     "the policy load; P: touch the policy lines of the workgroup P groups ahead); run for every --blocks geometry")
     ap.add_argument("--trace-variants", default="", help="variants (of the product geometry) to trace as well")
+    ap.add_argument("--gloop", default="", help="G-loop experiment: (threads)x(G)x(dim) triples, e.g. 256x4x1,256x8x1,640x4x1")
     ap.add_argument("--extra-flags", default="", help="extra hipcc flags for the diagnostic kernels, space separated")
     args = ap.parse_args()
 
@@ -525,6 +580,9 @@ def main():
                 print(blk, "trace" if tr_on else "plain", json.dumps(build(text, tr_on, blk, tmp, f"c{blk}_{tr_on}")[1]))
         fits = [affine_fit(b) for b in tables]
         print("affine fits", fits)
+        for triple in [t for t in args.gloop.split(",") if t]:
+            b, g, dim = (int(v) for v in triple.split("x"))
+            print("gloop", triple, json.dumps(build(text, 0, b, tmp, f"g{b}_{g}_{dim}", f"#define PT_G {g}\n#define PT_GDIM {dim}\n")[1].get("pt_eval_gloop_kernel")))
         for v in [v for v in args.variants.split(",") if v]:
             m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
             d = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
@@ -552,8 +610,9 @@ def main():
     pol = solver.d_policy
     block, cpw = eng.info(11), eng.info(3)
     src_text = eng.kernel_source(envs.dynamics_source(args.env))
+    user_tables = [np.asarray(b, np.float32) for b in cls.bins_space(args.bins).values()]
     tab = torch.from_numpy(np.concatenate([np.asarray(solver.action_space, np.float32)] +
-                                          [np.asarray(b, np.float32) for b in cls.bins_space(args.bins).values()])).cuda()
+                                          [user_tables[d] for d in eng.order])).cuda()      # the engine's memory order
     Vref = torch.empty_like(V)
     Vout = torch.empty_like(V)
     stream = torch.cuda.current_stream().cuda_stream
@@ -571,12 +630,15 @@ def main():
     count = torch.zeros(1, dtype=torch.int32, device="cuda:0")
     summary = {"product_ms": ms_product}
 
-    def run_variant(tag, trace_on, blk, cpw_v, persistent_w, it0, defines=""):
+    def run_variant(tag, trace_on, blk, cpw_v, persistent_w, it0, defines="", gloop=0):
         hsaco, usage = build(src_text, trace_on, blk, tmp, tag, defines)
         mod = Module(hsaco)
-        name = "pt_eval_persistent_kernel" if persistent_w else "pt_eval_kernel"
+        name = "pt_eval_gloop_kernel" if gloop else "pt_eval_persistent_kernel" if persistent_w else "pt_eval_kernel"
         f = mod.fn(name)
-        if persistent_w:
+        if gloop:
+            tiles = n // (blk * gloop)
+            blocks = max(8, 8 * ((tiles + 7) // 8))
+        elif persistent_w:
             blocks = 8 * persistent_w
         else:
             chunks = (n + blk - 1) // blk
@@ -594,6 +656,7 @@ def main():
         lines.append(f"{tag:36s}{ms:.4f} ms   V' == product: {same}   {blocks} workgroups x {blk}   "
                      f"VGPRs {u.get('VGPRs')} SGPRs {u.get('TotalSGPRs')} scratch {u.get('ScratchSize [bytes/lane]', u.get('ScratchSize'))} occupancy {u.get('Occupancy [waves/SIMD]', u.get('Occupancy'))}")
         summary[tag] = {"ms": ms, "identical": same, "usage": u}
+        print(lines[-1], flush=True)
         if trace_on:
             count.zero_()
             trace.zero_()
@@ -616,7 +679,7 @@ def main():
         run_variant(f"copy {b}x{c}", 0, b, c, 0, 0)
         geoms.append((b, c))
 
-    fits = [affine_fit(np.asarray(b, np.float32)) for b in cls.bins_space(args.bins).values()]
+    fits = [affine_fit(user_tables[d]) for d in eng.order]
 
     def defs(v):
         m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
@@ -629,6 +692,9 @@ def main():
     for v in [v for v in args.variants.split(",") if v]:
         for b, c in geoms:
             run_variant(f"{v} {b}x{c}", 0, b, c, 0, 0, defs(v))
+    for triple in [t for t in args.gloop.split(",") if t]:
+        b, g, dim = (int(v) for v in triple.split("x"))
+        run_variant(f"gloop {b} threads x G={g} along dim {dim}", 0, b, 1, 0, 0, f"#define PT_G {g}\n#define PT_GDIM {dim}\n", gloop=g)
     for v in [v for v in args.trace_variants.split(",") if v]:
         recs.append((f"{v} {block}x{cpw} traced", run_variant(f"{v} {block}x{cpw} traced", 1, block, cpw, 0, 0, defs(v))))
     first = True
