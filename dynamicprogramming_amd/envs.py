@@ -476,9 +476,10 @@ class DoubleCartPoleCuda(CudaPolicyIteration6D):
     (terminal mask); config gamma .999 / 10 000 / 200."""
 
     DEFAULT_BINS = 15
-    # device memory order (x, x_dot, theta1, th1_dot, th2_dot, theta2): 25^6 evaluation sweep 3.68 -> 3.29 ms
+    # device memory order (x, theta1, th1_dot, th2_dot, theta2, x_dot) — the cart's speed along the lanes, its position
+    # still the slowest dimension (the one multi-GPU shards are slabs of): 25^6 evaluation sweep 3.68 -> 3.07 ms
     # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt)
-    MEMORY_ORDER = (0, 1, 2, 3, 5, 4)
+    MEMORY_ORDER = (0, 2, 3, 5, 4, 1)
     ACTIONS = np.array([-10.0, 0.0, 10.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=10_000, max_pi_iter=200, log_interval=500)
     _TH_FAIL = 20.0 * np.pi / 180.0
@@ -528,9 +529,11 @@ class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
     reward shaping), :241-245 (terminal mask); config gamma .999 / 20 000 / 300."""
 
     DEFAULT_BINS = 20
-    # device memory order (x, theta1, th1_dot, x_dot, theta2, th2_dot): 25^6 evaluation sweep 7.84 -> 7.16 ms
-    # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt)
-    MEMORY_ORDER = (0, 2, 3, 1, 4, 5)
+    # device memory order (x, theta2, th2_dot, theta1, th1_dot, x_dot) — x_dot along the lanes (a wave's 64 successors
+    # then share their cell along every other dimension), x still the slowest: 25^6 evaluation sweep 7.84 -> 5.38 ms,
+    # improvement 35.2 -> 28.9 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt; (4, 5, 2, 3, 0, 1) is another
+    # 4 % faster but would make the multi-GPU slabs slabs of a wrapping angle)
+    MEMORY_ORDER = (0, 4, 5, 2, 3, 1)
     ACTIONS = np.array([-60.0, -30.0, -10.0, -3.0, 0.0, 3.0, 10.0, 30.0, 60.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=20_000, max_pi_iter=300, log_interval=500)
 
