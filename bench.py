@@ -788,6 +788,9 @@ def main() -> None:
                   "eval_threads_per_workgroup": eng.info(11), "eval_chunks_per_workgroup": eng.info(3),
                   "improve_threads_per_workgroup": eng.info(12), "improve_chunks_per_workgroup": eng.info(8),
                   "interpolation_reciprocal_division": [eng.info(20 + d) for d in range(D)],
+                  "memory_order": {"order": list(eng.order), "dimensions": [solver._bin_keys[d] for d in eng.order],
+                                   "note": "device arrays hold the grid with its dimensions in this order (slowest first); "
+                                           "host-side arrays and all arithmetic stay in the env's own order"},
                   "exchange": exchange},
     }
     if rank == 0 and not args.no_cpu_baseline:            # rank 0's host cores; the other ranks wait at the barrier below

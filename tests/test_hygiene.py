@@ -88,6 +88,17 @@ def test_committed_bench_evidence_matches_the_kernels_and_the_contract():
         cb = d["cpu_baseline"]
         for key in ("value", "unit", "cores", "kind", "sample"):
             assert key in cb, (path.name, key)
+        if int(latest.name[1:]) >= 4:
+            # round 4: the line says what it measured — terminal states counted or not, which thread count the CPU
+            # figure is for, and what "compulsory" bytes mean on this grid
+            assert d["value_nonterminal"] <= d["value"] * (1 + 1e-12) and c["nonterminal_states"] <= c["states"]
+            assert abs(d["value_nonterminal"] * c["states"] - d["value"] * c["nonterminal_states"]) <= 1e-9 * d["value"] * c["states"]
+            assert "terminal" in c["workload"]
+            for key in ("value_all_affinity_threads", "affinity_threads", "value_16_threads", "value_1_thread"):
+                assert key in cb, (path.name, key)
+            assert cb["value"] == max(cb["value_all_affinity_threads"], cb["value_16_threads"])
+            assert d["roofline"]["compulsory_bytes_per_state"] in (12.0, 13.0)
+            assert "memory_order" in d["check"]
         r = d["roofline"]
         for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert key in r, (path.name, key)
