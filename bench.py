@@ -296,8 +296,11 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
         for k, (mode, extra) in enumerate(ladder):
             port = [_free_port() if rank == 0 else None]          # the ranks' own rendezvous: a fresh port per rung
             dist.broadcast_object_list(port, src=0)
-            env = {**os.environ, **extra, "PI_BENCH_WORKER": "1", "PI_BENCH_ATTEMPT": str(k), "PI_BENCH_MODE": mode,
-                   "MASTER_PORT": str(port[0])}
+            # The child rendezvouses on its OWN port with rank 0 hosting the store: the launcher's agent store
+            # (TORCHELASTIC_USE_AGENT_STORE) lives on the launcher's port and belongs to the supervisors.
+            env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC_")}
+            env.update({**extra, "PI_BENCH_WORKER": "1", "PI_BENCH_ATTEMPT": str(k), "PI_BENCH_MODE": mode,
+                        "MASTER_PORT": str(port[0])})
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             proc = subprocess.Popen(worker_command(argv), env=env, text=True, start_new_session=True,
                                     stdout=subprocess.PIPE if rank == 0 else sys.stderr)

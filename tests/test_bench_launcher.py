@@ -173,3 +173,40 @@ def test_self_launch_kills_a_child_that_overruns(monkeypatch):
     monkeypatch.setattr(bench.subprocess, "Popen", Quick)
     assert bench.self_launch(2, ["--gpus", "2"], dry_run=False) == 124
     assert _t.monotonic() - t0 < 60
+
+
+def test_under_the_real_launcher_the_ranks_children_can_rendezvous(tmp_path):
+    """The contract's launch line for real: torch.distributed.run starts two supervisors, each starts a child rank, and
+    the CHILDREN form their own process group (gloo here) on the port the supervisors agreed on — which only works if the
+    child does not inherit the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE points at the launcher's port)."""
+    import os
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(
+        "import json, os, torch, torch.distributed as dist\n"
+        "assert os.environ['PI_BENCH_WORKER'] == '1' and 'TORCHELASTIC_USE_AGENT_STORE' not in os.environ\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.ones(1)\n"
+        "dist.all_reduce(t)\n"
+        "assert t.item() == dist.get_world_size() == 2\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'metric': 'm', 'value': 2.0, 'n_gpus': 2, 'check': {'exchange': {'mode': os.environ['PI_BENCH_MODE']}}}))\n"
+        "dist.destroy_process_group()\n")
+    driver = tmp_path / "supervisor.py"
+    driver.write_text(
+        "import importlib.util, sys\n"
+        f"spec = importlib.util.spec_from_file_location('bench_under_test', r'{ROOT / 'bench.py'}')\n"
+        "bench = importlib.util.module_from_spec(spec)\n"
+        "spec.loader.exec_module(bench)\n"
+        f"bench.worker_command = lambda argv: [sys.executable, r'{fake}']\n"
+        "sys.exit(bench.supervise(['--gpus', '2'], attempt_timeout=90.0))\n")
+    bench = _bench()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(bench._free_port()), str(driver)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = bench.result_line(res.stdout)
+    assert line is not None, res.stdout
+    obj = json.loads(line)
+    assert obj["value"] == 2.0 and [a["ok"] for a in obj["check"]["exchange"]["attempts"]] == [True]
+    assert obj["check"]["exchange"]["attempts"][0]["mode"] == "halo+overlap"

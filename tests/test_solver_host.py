@@ -294,3 +294,23 @@ def test_memory_order_applies_to_big_grids_only():
     for name, c in envs.ENVS.items():
         if c.MEMORY_ORDER is not None:
             assert sorted(c.MEMORY_ORDER) == list(range(c._D)), name
+
+
+def test_sharded_solvers_keep_the_envs_order_unless_forced(monkeypatch):
+    """The fast single-GPU orders widen a shard's halo (a band of planes instead of a triangle of rows), so a rank of a
+    sharded run stays in the env's order; PI_MI355_ORDER still forces one."""
+    cls = envs.ENVS["double_pendulum_swingup"]
+    s = object.__new__(cls)
+    s.n_states, s._process_group = 1 << 25, None
+
+    class TwoRanks:
+        world, rank = 2, 0
+    s._transport_arg = None
+    assert s._choose_memory_order() == tuple(cls.MEMORY_ORDER)          # single rank, big grid
+    s._transport_arg = TwoRanks()
+    assert s._will_shard() and s._choose_memory_order() is None
+    s._transport_arg = False
+    assert not s._will_shard() and s._choose_memory_order() == tuple(cls.MEMORY_ORDER)
+    s._transport_arg = TwoRanks()
+    monkeypatch.setenv("PI_MI355_ORDER", "0,2,1,3")
+    assert s._choose_memory_order() == (0, 2, 1, 3)
