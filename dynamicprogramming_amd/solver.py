@@ -267,7 +267,9 @@ class _CudaPolicyIterationBase(abc.ABC):
         env = os.environ.get("PI_MI355_ORDER", "").strip().lower()
         if env in ("user", "identity", "none"):
             return None
-        if env:
+        if env == "auto":
+            order = self._probe_memory_order()
+        elif env:
             order = tuple(int(v) for v in env.split(","))
         elif self.MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES and not self._will_shard():
             order = tuple(self.MEMORY_ORDER)
@@ -276,6 +278,54 @@ class _CudaPolicyIterationBase(abc.ABC):
         if sorted(order) != list(range(self._D)):
             raise ValueError(f"memory order {order} is not a permutation of the {self._D} dimensions")
         return None if order == tuple(range(self._D)) else order
+
+    def _probe_memory_order(self, samples: int = 192, seed: int = 0):
+        """PI_MI355_ORDER=auto — pick the LANE dimension of an env nobody has tuned, from its own dynamics.  For every
+        candidate d >= 1 the plugin is evaluated (pi_probe_step / pi_probe_interp on the device, a throw-away handle) on
+        `samples` runs of up to 64 consecutive grid points along d, everything else random: the best lane dimension is the
+        one along which a wave's successors stay together, i.e. with the smallest mean spread of the successor cell over
+        the OTHER dimensions (double cartpole: 0.9 cells with x_dot along the lanes, 5-9 with an angle or an angular
+        speed — and x_dot is what tools/dim_order_sweep.py finds, -17 % / -31 % per evaluation sweep; double pendulum:
+        16-20 cells whatever the lane dimension, the env's own last dimension stays).  Dimension 0 stays the slowest
+        (sharding) and the others keep their order.  A heuristic for the lane dimension only; measure with the tool."""
+        import torch
+        D, shape = self._D, [len(b) for b in self._bins]
+        dev = torch.device("cuda", torch.cuda.current_device() if self._device_arg is None
+                           else torch.device(self._device_arg).index or 0)
+        eng = _native.Engine(D, self.grid_shape, self.bounds_low, self.bounds_high, self._bins, self.action_space,
+                             device=dev.index)
+        try:
+            eng.compile(self._dynamics_cuda_src())
+            rng = np.random.default_rng(seed)
+            spread = {}
+            for d in range(1, D):
+                L = min(64, shape[d])
+                idx = np.stack([rng.integers(0, shape[k], samples) for k in range(D)], axis=1)
+                idx = np.repeat(idx[:, None, :], L, axis=1)
+                idx[:, :, d] = rng.integers(0, shape[d] - L + 1, samples)[:, None] + np.arange(L)[None, :]
+                pts = np.stack([self._bins[k][idx[:, :, k]] for k in range(D)], axis=-1).reshape(-1, D).astype(np.float32)
+                act = np.repeat(rng.choice(self.action_space, samples), L).astype(np.float32)
+                m = len(pts)
+                d_pts, d_act = torch.from_numpy(pts).to(dev), torch.from_numpy(act).to(dev)
+                d_next = torch.empty((m, D), dtype=torch.float32, device=dev)
+                d_rew = torch.empty(m, dtype=torch.float32, device=dev)
+                d_done = torch.empty(m, dtype=torch.uint8, device=dev)
+                d_idx = torch.empty((m, 1 << D), dtype=torch.int32, device=dev)
+                d_w = torch.empty((m, 1 << D), dtype=torch.float32, device=dev)
+                st = torch.cuda.current_stream(dev).cuda_stream
+                eng.probe_step(d_pts.data_ptr(), d_act.data_ptr(), d_next.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), m, st)
+                eng.probe_interp(d_next.data_ptr(), d_idx.data_ptr(), d_w.data_ptr(), m, st)
+                torch.cuda.synchronize(dev)
+                base = d_idx[:, 0].cpu().numpy().astype(np.int64)           # lowest corner of the successor cell (env order here)
+                cell = np.stack(np.unravel_index(base, shape), axis=1).reshape(samples, L, D)
+                spread[d] = float(sum((cell[:, :, k].max(1) - cell[:, :, k].min(1)).mean() for k in range(D) if k != d))
+        finally:
+            eng.close()
+        lane = min(range(1, D), key=lambda d: (spread[d], -d))              # ties: the env's own last dimension
+        order = tuple([k for k in range(D) if k != lane] + [lane])
+        logger.info(f"memory order (auto): spread of a wave's successors over the other dimensions, by lane dimension: "
+                    f"{ {self._bin_keys[d]: round(v, 2) for d, v in spread.items()} } -> lanes along {self._bin_keys[lane]}")
+        return order
 
     def _to_memory(self, a):
         """Whole-grid array in the user's order -> the device's memory order (identity without MEMORY_ORDER)."""

@@ -1097,3 +1097,29 @@ def test_memory_order_full_runs_equal_the_oracle(name, shape, order, world, cuda
         V, pol, sweeps = out[r]
         H.assert_bits_equal(V, ref["value_function"], f"rank {r} V")
         assert np.array_equal(pol, ref["policy"]) and sweeps == list(ref["sweeps_per_iter"])
+
+
+@pytest.mark.parametrize("name,bins,lane", [("double_cartpole_swingup", 11, 1), ("double_cartpole", 11, 1),
+                                             ("double_pendulum_swingup", 24, None), ("pendulum", 40, None)])
+def test_memory_order_auto_picks_a_lane_dimension_from_the_dynamics(name, bins, lane, cuda_device, monkeypatch):
+    """PI_MI355_ORDER=auto: the lane dimension of an env nobody tuned is the one along which a wave's successors stay
+    together (measured on the device with the plugin itself); for the double cartpole that is the cart's speed — what
+    the exhaustive measurement finds — dimension 0 stays slowest, and the run's results are the oracle's in any case."""
+    monkeypatch.setenv("PI_MI355_ORDER", "auto")
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 2, "max_eval_iter": 40}
+    s = cls(cls.bins_space(bins), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
+    order = s._order if s._order is not None else tuple(range(cls._D))
+    assert sorted(order) == list(range(cls._D)) and order[0] == 0
+    if lane is not None:
+        assert order[-1] == lane and list(order[:-1]) == [d for d in range(cls._D) if d != lane]
+    s.run()
+    tables = H.env_bins(name, (bins,) * cls._D)
+    lo, hi, gshape, strides = oracle.grid_metadata(tables)
+    states = oracle.states_from_bins(tables)
+    term, tval = H.terminal_mask(name, states)
+    cfg = envs.CudaPIConfig(**cfg_kw)
+    ref = H.oracle_for(name).run(states, cls.ACTIONS, term, lo, hi, gshape, strides, gamma=cfg.gamma, theta=cfg.theta,
+                                 max_eval_iter=cfg.max_eval_iter, max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
+    H.assert_bits_equal(s.value_function, ref["value_function"], f"{name} auto order {order}")
+    assert np.array_equal(s.policy, ref["policy"]) and s.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
