@@ -203,15 +203,17 @@ def numpy_reference_c1() -> dict:
             "config": "Pendulum 50 x 50 x 11 actions, numpy float32, one thread"}
 
 
-def load_profile(env: str, bins: int, n_states: int, kernel_hash: str, label: str = "bench"):
-    """Latest committed PMC profile (tools/profile_config.sh) of this config — env, bins — on the bench
-    (or policy-iteration: label "real") state whose kernel hash is the current one."""
+def load_profile(env: str, bins: int, n_states: int, kernel_hash: str, label: str = "bench", order=None):
+    """Latest committed PMC profile (tools/profile_config.sh) of this config — env, bins, memory order of the
+    dimensions — on the bench (or policy-iteration: label "real") state whose kernel hash is the current one."""
     for path in sorted(ROOT.glob(f"profiles/r*/counters_{label}_*.json"), reverse=True):
         try:
             prof = json.loads(path.read_text())
         except (OSError, ValueError):
             continue
         if prof.get("kernel_source_hash") != kernel_hash or prof.get("states", n_states) != n_states:
+            continue
+        if order is not None and list(prof.get("memory_order", range(len(order)))) != list(order):
             continue
         if prof.get("env", ENV) == env and prof.get("bins", BINS) == bins:
             return prof, str(path.relative_to(ROOT))
@@ -619,7 +621,7 @@ def main() -> None:
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
-    prof, prof_path = load_profile(args.env, args.bins, n, khash)
+    prof, prof_path = load_profile(args.env, args.bins, n, khash, order=eng.order)
     # N > 1: the committed profile is the single-GPU launch of the same kernel; per-wave figures carry over, the number
     # of waves (and every per-launch total) scales with this rank's share of the states
     prof_scale = states_per_launch / float(n)
@@ -699,7 +701,7 @@ def main() -> None:
         }
     if converged:
         # the same units for the policy-iteration state, from ITS committed counters
-        rprof, rpath = load_profile(args.env, args.bins, n, khash, "real")
+        rprof, rpath = load_profile(args.env, args.bins, n, khash, "real", order=eng.order)
         if rprof:
             conv = kernel_entry("pi_eval_sweep_kernel", converged["ms"], states_per_launch, bytes_eval,
                                 counters=rprof.get("kernels", {}))

@@ -476,10 +476,11 @@ class DoubleCartPoleCuda(CudaPolicyIteration6D):
     (terminal mask); config gamma .999 / 10 000 / 200."""
 
     DEFAULT_BINS = 15
-    # device memory order (x, theta1, th1_dot, th2_dot, theta2, x_dot) — the cart's speed along the lanes, its position
-    # still the slowest dimension (the one multi-GPU shards are slabs of): 25^6 evaluation sweep 3.68 -> 3.07 ms
-    # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt)
-    MEMORY_ORDER = (0, 2, 3, 5, 4, 1)
+    # device memory order (th2_dot, theta2, theta1, th1_dot, x, x_dot) — the cart's speed along the lanes (a wave's 64
+    # successors then share their cell along every other dimension), its position next to it: 25^6 evaluation sweep
+    # 3.68 -> 2.87 ms, improvement 7.19 -> 6.88 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt; with x kept
+    # slowest, (0, 2, 3, 5, 4, 1): 3.07 / 7.11).  Single-rank solvers only: sharded ones keep the env's order.
+    MEMORY_ORDER = (5, 4, 2, 3, 0, 1)
     ACTIONS = np.array([-10.0, 0.0, 10.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=10_000, max_pi_iter=200, log_interval=500)
     _TH_FAIL = 20.0 * np.pi / 180.0
@@ -529,11 +530,10 @@ class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
     reward shaping), :241-245 (terminal mask); config gamma .999 / 20 000 / 300."""
 
     DEFAULT_BINS = 20
-    # device memory order (x, theta2, th2_dot, theta1, th1_dot, x_dot) — x_dot along the lanes (a wave's 64 successors
-    # then share their cell along every other dimension), x still the slowest: 25^6 evaluation sweep 7.84 -> 5.38 ms,
-    # improvement 35.2 -> 28.9 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt; (4, 5, 2, 3, 0, 1) is another
-    # 4 % faster but would make the multi-GPU slabs slabs of a wrapping angle)
-    MEMORY_ORDER = (0, 4, 5, 2, 3, 1)
+    # device memory order (theta2, th2_dot, theta1, th1_dot, x, x_dot) — x_dot along the lanes, x next to it: 25^6
+    # evaluation sweep 7.84 -> 5.16 ms, improvement 35.2 -> 24.3 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt;
+    # with x kept slowest, (0, 4, 5, 2, 3, 1): 5.38 / 28.9).  Single-rank solvers only: sharded ones keep the env's order.
+    MEMORY_ORDER = (4, 5, 2, 3, 0, 1)
     ACTIONS = np.array([-60.0, -30.0, -10.0, -3.0, 0.0, 3.0, 10.0, 30.0, 60.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=20_000, max_pi_iter=300, log_interval=500)
 

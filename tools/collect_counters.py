@@ -30,6 +30,17 @@ def n_states():
     return n
 
 
+def memory_order():
+    """The memory order of the dimensions a single-rank solver of (ENV, BINS) uses (class default / PI_MI355_ORDER)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dynamicprogramming_amd import envs
+    cls = envs.ENVS[ENV]
+    s = object.__new__(cls)
+    s.n_states, s._transport_arg, s._process_group = n_states(), False, None
+    order = os.environ.get("PI_MI355_ORDER", "") != "auto" and s._choose_memory_order()
+    return list(order) if order else list(range(cls._D))
+
+
 def passes(label):
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     durations = collections.defaultdict(list)
@@ -78,7 +89,7 @@ cal = None
 for label in labels:
     counters, durations = passes(label)
     res = {"label": label, "kernel_source_hash": head_hash(), "dispatches_averaged": LAST,
-           "env": ENV, "bins": BINS, "states": n_states(),
+           "env": ENV, "bins": BINS, "states": n_states(), "memory_order": memory_order(),
            "valu_peak_measured_Ginst_per_s": measured_valu_peak(), "kernels": {}}
     for k in sorted(counters):
         c = {name: sum(v) / len(v) for name, v in counters[k].items() if v}

@@ -50,6 +50,9 @@ PT_KERNELS = r'''
 #ifndef PT_AFFINE
 #define PT_AFFINE 0
 #endif
+#ifndef PT_LDSBOX
+#define PT_LDSBOX 0
+#endif
 // PT_WPRIO: issue priority by position in the workgroup.  The arbiter prefers the oldest wave, so the 16 waves of a
 // workgroup drift apart in index order and the first ones leave their slots empty for thousands of cycles before the
 // last one frees the workgroup's resources.  1: base priority = wave / 4 (0..3), 3 while the gather is in flight;
@@ -229,9 +232,44 @@ __device__ __forceinline__ void pt_eval_body(const float* __restrict__ V, float*
 #if PT_TRACE
         if (rec) PT_STAMP2(2);                    // C: dynamics + cell search issued
 #endif
+#if PT_LDSBOX
+        // TIMING ONLY (results are wrong): what the gather would cost if the wave fetched the box of V its successors
+        // fall into with COALESCED 16-byte loads into LDS (PT_LDSBOX dwords per state) and every lane then read its
+        // 2^(D-1) corner pairs from there at lane-consecutive addresses — the shape the gather has once the lanes of a
+        // wave share their successor cell along every dimension but the lane dimension (memory order, DESIGN.md s. 3).
+        {
+            constexpr int kSeg = PI_NPAIR, kLen = 72;                 // one segment per corner pair, 64 + slack floats
+            __shared__ float lds_box[PI_BLOCK_EVAL / 64][kSeg * kLen];
+            float* box = lds_box[tid >> 6];
+            const unsigned int l = tid & 63u;
+            const unsigned int base0 = __builtin_amdgcn_readfirstlane(base);
+            constexpr int kLoads = (PT_LDSBOX * 64 + 255) / 256;      // wave-wide 16-byte loads
+#pragma unroll
+            for (int it = 0; it < kLoads; ++it) {
+                unsigned int off = base0 + (unsigned int)((it * 64 + l) * 4);
+                off = off < (unsigned int)(PI_GRID.n - 4) ? off : 0u;
+                const float4 q = *reinterpret_cast<const float4*>(V + (off & ~3u));
+                if ((it * 64 + l) * 4 + 3 < kSeg * kLen) *reinterpret_cast<float4*>(box + (it * 64 + l) * 4) = q;
+            }
+            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_wave_barrier();
+            PiPair vp[PI_NPAIR];
+            const unsigned int drift = (base - base0) & 7u;
+#pragma unroll
+            for (int m = 0; m < PI_NPAIR; ++m) {
+                vp[m].x = box[m * kLen + l + drift];
+                vp[m].y = box[m * kLen + l + drift + 1];
+            }
+            e = done ? 0.0f : pi_combine_corners(vp, fr);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (false) {
+            PiPair vp[PI_NPAIR];
+#else
         if (!done) {
             PiPair vp[PI_NPAIR];
             pi_request_corners(V, base, vp);
+#endif
 #if PT_TRACE
             if (rec) PT_STAMP2(3);                // D: the 2^(D-1) corner loads issued
 #endif
@@ -563,6 +601,9 @@ def main():
                     "the policy load; P: touch the policy lines of the workgroup P groups ahead); run for every --blocks geometry")
     ap.add_argument("--trace-variants", default="", help="variants (of the product geometry) to trace as well")
     ap.add_argument("--gloop", default="", help="G-loop experiment: (threads)x(G)x(dim) triples, e.g. 256x4x1,256x8x1,640x4x1")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="allow grids with terminal states (the copies treat every state as live) and variants whose results "
+                         "are wrong on purpose (L<n>: corner values from an LDS box filled with n coalesced dwords per state)")
     ap.add_argument("--extra-flags", default="", help="extra hipcc flags for the diagnostic kernels, space separated")
     args = ap.parse_args()
 
@@ -584,8 +625,9 @@ def main():
             b, g, dim = (int(v) for v in triple.split("x"))
             print("gloop", triple, json.dumps(build(text, 0, b, tmp, f"g{b}_{g}_{dim}", f"#define PT_G {g}\n#define PT_GDIM {dim}\n")[1].get("pt_eval_gloop_kernel")))
         for v in [v for v in args.variants.split(",") if v]:
-            m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
-            d = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
+            m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?(?:L(\d+))?", v)
+            d = (f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
+                 f"#define PT_LDSBOX {m.group(5) or 0}\n")
             if m.group(1):
                 d += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
                       "#define PT_AFF_B_INIT {" + ",".join(float(f[1]).hex() for f in fits) + "}\n")
@@ -596,7 +638,8 @@ def main():
     eng = solver._backend.engine
     n, nA = solver.n_states, solver.n_actions
     gamma = float(np.float32(solver.config.gamma))
-    assert solver.d_terminal_mask is None or not bool(solver.d_terminal_mask.any()), "traced copy: grids without terminal states"
+    if not args.timing_only:
+        assert solver.d_terminal_mask is None or not bool(solver.d_terminal_mask.any()), "traced copy: grids without terminal states"
     gen = torch.Generator(device="cpu").manual_seed(0)
     V = solver.d_value_function
     V[:n].copy_(torch.randn(n, generator=gen, dtype=torch.float32))
@@ -682,8 +725,9 @@ def main():
     fits = [affine_fit(user_tables[d]) for d in eng.order]
 
     def defs(v):
-        m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?", v)
-        text = f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
+        m = re.fullmatch(r"(A?)R(\d)P(\d+)(?:W(\d))?(?:L(\d+))?", v)
+        text = (f"#define PT_REORDER {m.group(2)}\n#define PT_PF_DIST {m.group(3)}\n#define PT_WPRIO {m.group(4) or 0}\n"
+                f"#define PT_LDSBOX {m.group(5) or 0}\n")
         if m.group(1):
             assert all(f is not None and not f[2] for f in fits), "a bin table of this env is not an exact affine float64 sequence"
             text += ("#define PT_AFFINE 1\n#define PT_AFF_A_INIT {" + ",".join(float(f[0]).hex() for f in fits) + "}\n"
