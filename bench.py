@@ -25,7 +25,7 @@ started by the launcher does not touch the GPU itself: it SUPERVISES.  Every ran
 gloo (CPU) group over the launcher's rendezvous and starts the real rank as a fresh child process
 (`PI_BENCH_WORKER=1`, its own rendezvous port agreed over gloo), once per rung of a fallback ladder —
 halo exchange overlapped with the interior sweep (the library's default) -> halo exchange without overlap
--> all-gather — each rung with a time limit (`--attempt-timeout`, 240 s).  The supervisors agree twice a
+-> all-gather -> all-gather with nothing optional in this script — each rung with a time limit (`--attempt-timeout`, 240 s).  The supervisors agree twice a
 second on "some rank failed / every rank is done / time is up" (a three-word all-reduce); a failed or
 late rung is killed everywhere (process groups) and the next one starts in new processes — a process that
 has touched the GPU is never re-executed.  Rank 0 relays the first successful line with
@@ -238,6 +238,9 @@ LADDER = [
     ("halo+overlap", {}),                                         # library default: halo unless it is > 60 % of an all-gather
     ("halo", {"PI_MI355_OVERLAP": "0"}),                          # whole shard, then the exchange on the same stream
     ("allgather", {"PI_MI355_EXCHANGE": "allgather", "PI_MI355_OVERLAP": "0"}),   # one ncclAllGather per sweep
+    # last resort — against a fault in this script's own N > 1 reporting rather than in the exchange: the same all-gather
+    # run with nothing optional in it (no self-check, no per-rank table, no CPU baseline, no profile look-up)
+    ("allgather-minimal", {"PI_MI355_EXCHANGE": "allgather", "PI_MI355_OVERLAP": "0", "PI_BENCH_MINIMAL": "1"}),
 ]
 ATTEMPT_TIMEOUT = 240.0
 
@@ -501,8 +504,11 @@ def main() -> None:
     n_live = n - int(solver.d_terminal_mask[:n].sum().item())     # non-terminal states: the ones a sweep backs up
 
     # ── N > 1: sharded sweeps against the unsharded sweeps of the same state, bit for bit, before anything is timed ──
+    minimal = os.environ.get("PI_BENCH_MINIMAL") == "1"        # last rung of the N > 1 ladder: nothing optional
     bit_identical = None
-    if world > 1:
+    if world > 1 and minimal:
+        bit_identical = {"ok": None, "skipped": "minimal rung of the fallback ladder"}
+    elif world > 1:
         bit_identical = sharded_equals_unsharded(solver, eng, gamma, torch, dist)
         if not bit_identical["ok"]:
             if rank == 0:
@@ -621,7 +627,7 @@ def main() -> None:
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     khash = _native.kernel_source_hash()
-    prof, prof_path = load_profile(args.env, args.bins, n, khash, order=eng.order)
+    prof, prof_path = (None, None) if minimal else load_profile(args.env, args.bins, n, khash, order=eng.order)
     # N > 1: the committed profile is the single-GPU launch of the same kernel; per-wave figures carry over, the number
     # of waves (and every per-launch total) scales with this rank's share of the states
     prof_scale = states_per_launch / float(n)
@@ -738,7 +744,11 @@ def main() -> None:
                                     "roofline.traffic — no fraction is quoted against this model"}
 
     exchange = None
-    if solver._comm is not None and getattr(solver._comm, "info", None):
+    if solver._comm is not None and getattr(solver._comm, "info", None) and minimal:
+        exchange = {"mode": solver._comm.info.get("mode"), "world": eng.comm_info(1), "bit_identical": bit_identical,
+                    "transport": {1: "rccl", 2: "in-process"}.get(eng.comm_info(2), "none"),
+                    "ladder_mode": os.environ.get("PI_BENCH_MODE"), "recv_elems": solver._comm.info.get("recv_elems")}
+    elif solver._comm is not None and getattr(solver._comm, "info", None):
         # what the driver needs to see that RCCL really ran with N ranks: the communicator's own view
         # (pi_comm_info), this rank's plan, and every rank's evaluation time and halo volume
         exchange = dict(solver._comm.info)
@@ -798,7 +808,7 @@ def main() -> None:
                                            "host-side arrays and all arithmetic stay in the env's own order"},
                   "exchange": exchange},
     }
-    if rank == 0 and not args.no_cpu_baseline:            # rank 0's host cores; the other ranks wait at the barrier below
+    if rank == 0 and not args.no_cpu_baseline and not minimal:   # rank 0's host cores; the other ranks wait at the barrier below
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -68,8 +68,9 @@ plan = json.loads(os.environ["FAKE_PLAN"])            # per attempt: what each r
 what = plan[attempt][rank] if attempt < len(plan) else "ok"
 if mode == "halo":
     assert os.environ.get("PI_MI355_OVERLAP") == "0"
-if mode == "allgather":
+if mode.startswith("allgather"):
     assert os.environ.get("PI_MI355_EXCHANGE") == "allgather"
+assert (os.environ.get("PI_BENCH_MINIMAL") == "1") == (mode == "allgather-minimal")
 if what == "hang":
     time.sleep(600)
 if what.startswith("exit"):
@@ -143,7 +144,7 @@ def test_a_hung_rung_is_killed_at_the_time_limit_and_the_ladder_ends_in_allgathe
 
 
 def test_when_every_rung_fails_every_rank_fails():
-    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"]], timeout=30.0)
+    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"], ["ok", "exit5"]], timeout=30.0)
     assert [rc for _, rc, _ in got] == [1, 1]
     assert all(out.strip() == "" for _, _, out in got)                  # no result line is invented
 
@@ -154,7 +155,8 @@ def test_dry_run_shows_the_ladder():
                                                       if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert res.returncode == 0, res.stderr
     obj = json.loads(res.stdout.strip().splitlines()[-1])
-    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap", "halo", "allgather"]
+    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap", "halo", "allgather", "allgather-minimal"]
+    assert obj["ladder"][3]["env"]["PI_BENCH_MINIMAL"] == "1"
     assert obj["ladder"][2]["env"]["PI_MI355_EXCHANGE"] == "allgather" and obj["ladder"][0]["timeout_s"] == 240.0
     assert obj["worker"][1].endswith("bench.py")
 
@@ -210,3 +212,12 @@ def test_under_the_real_launcher_the_ranks_children_can_rendezvous(tmp_path):
     obj = json.loads(line)
     assert obj["value"] == 2.0 and [a["ok"] for a in obj["check"]["exchange"]["attempts"]] == [True]
     assert obj["check"]["exchange"]["attempts"][0]["mode"] == "halo+overlap"
+
+
+def test_the_minimal_rung_is_the_last_resort():
+    got = _run_supervisors([["exit1", "ok"], ["ok", "exit1"], ["exit1", "exit1"], ["ok", "ok"]], timeout=30.0)
+    (_, rc0, out0), (_, rc1, _) = got
+    assert (rc0, rc1) == (0, 0)
+    att = json.loads(out0.strip().splitlines()[-1])["check"]["exchange"]["attempts"]
+    assert [a["mode"] for a in att] == ["halo+overlap", "halo", "allgather", "allgather-minimal"]
+    assert [a["ok"] for a in att] == [False, False, False, True]
