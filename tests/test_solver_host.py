@@ -314,3 +314,63 @@ def test_sharded_solvers_keep_the_envs_order_unless_forced(monkeypatch):
     s._transport_arg = TwoRanks()
     monkeypatch.setenv("PI_MI355_ORDER", "0,2,1,3")
     assert s._choose_memory_order() == (0, 2, 1, 3)
+
+
+# ── property tests (hypothesis): the index algebra of the memory order and of the exchange planner ───────
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@st.composite
+def _grids(draw):
+    D = draw(st.sampled_from([2, 4, 6]))
+    shape = [draw(st.integers(2, 5 if D == 6 else 7)) for _ in range(D)]
+    order = draw(st.permutations(list(range(D))))
+    return D, shape, tuple(order)
+
+
+@settings(max_examples=25, deadline=None)
+@given(_grids())
+def test_memory_order_index_algebra(grid):
+    """to_memory / to_user are inverse permutations of the flat index, and memory index m holds the state whose
+    coordinates along the engine's memory dimensions are the row-major digits of m over the permuted shape."""
+    from dynamicprogramming_amd import _native
+    D, shape, order = grid
+    bins = [np.linspace(-1.0 - d, 1.0 + d, g, dtype=np.float32) for d, g in enumerate(shape)]
+    eng = _native.Engine(D, shape, [b.min() for b in bins], [b.max() for b in bins], bins, [0.0, 1.0], device=-1, order=order)
+    try:
+        n = int(np.prod(shape))
+        user = np.arange(n, dtype=np.int64)
+        mem = np.asarray(eng.to_memory(user))
+        assert sorted(mem.tolist()) == list(range(n))
+        assert np.array_equal(np.asarray(eng.to_user(mem)), user)
+        digits_user = np.stack(np.unravel_index(mem, shape), axis=1)                 # user coordinates of memory slot m
+        mshape = [shape[d] for d in eng.order]
+        digits_mem = np.stack(np.unravel_index(np.arange(n), mshape), axis=1)        # memory coordinates of slot m
+        for k, d in enumerate(eng.order):
+            assert np.array_equal(digits_mem[:, k], digits_user[:, d])
+        assert eng.info(18) == sum(d << (3 * k) for k, d in enumerate(eng.order))
+    finally:
+        eng.close()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 5), st.integers(3, 24), st.integers(1, 9), st.data())
+def test_exchange_planner_sends_exactly_what_is_reachable(world, g0, stride0, data):
+    """pi_plan_segments (host-only): every (dst, unit) a rank can reach and does not own arrives exactly once, from its
+    owner; nothing else travels; no rank sends to itself."""
+    from dynamicprogramming_amd import _native
+    n = g0 * stride0 - data.draw(st.integers(0, stride0 - 1))                       # a ragged last unit
+    per = -(-n // world)
+    reach = np.array(data.draw(st.lists(st.lists(st.booleans(), min_size=g0, max_size=g0), min_size=world, max_size=world)))
+    segs = _native.plan_segments(world, g0, stride0, n, per, reach)
+    got = np.zeros((world, n), dtype=np.int32)
+    for src, dst, a, b in segs:
+        assert src != dst and 0 <= a < b <= n
+        assert src * per <= a and b <= min((src + 1) * per, n)                      # the sender owns what it sends
+        got[dst, a:b] += 1
+    for dst in range(world):
+        need = np.zeros(n, dtype=bool)
+        for p in np.flatnonzero(reach[dst]):
+            need[p * stride0:min((p + 1) * stride0, n)] = True
+        need[dst * per:min((dst + 1) * per, n)] = False                             # its own shard does not travel
+        assert np.array_equal(got[dst] > 0, need) and got[dst].max(initial=0) <= 1
