@@ -39,11 +39,11 @@ def seed(solver):
     gen = torch.Generator(device="cpu").manual_seed(0)
     V = torch.randn(n, generator=gen, dtype=torch.float32)
     P = torch.randint(0, solver.n_actions, (n,), generator=gen, dtype=torch.int32)
-    solver.d_value_function[:n].copy_(V)
+    solver.d_value_function[:n].copy_(solver._to_memory(V))        # the same problem whatever the solver's memory order
     term = solver.d_terminal_mask[:n].bool()
     solver.d_value_function[:n][term] = 0.0
     solver.d_new_value_function.copy_(solver.d_value_function)
-    solver.d_policy[:n].copy_(P)
+    solver.d_policy[:n].copy_(solver._to_memory(P))
     solver.d_policy[:n][term] = 0
 
 
@@ -60,8 +60,9 @@ e1.synchronize()
 whole_ms = e0.elapsed_time(e1) / sweeps
 single._improvement_sweep(gamma)
 torch.cuda.synchronize()
-V_ref = single.d_value_function[:n].clone()
-P_ref = single.d_policy[:n].clone()
+# the single-rank solver may hold its arrays in the class's fast memory order; sharded ranks keep the env's order
+V_ref = single._to_user(single.d_value_function[:n]).clone()
+P_ref = single._to_user(single.d_policy[:n]).clone()
 changed_ref = int(single._d_changed.item())
 delta_ref = float(single._d_delta.item())
 

@@ -53,8 +53,9 @@ for name, bins in cases:
     torch.cuda.synchronize()
     t_vi = time.perf_counter() - t0
     sweeps_vi = vi.stats["value_sweeps"]
-    V_vi = vi.d_value_function[:vi.n_states].cpu().numpy()
-    P_vi = vi.d_policy[:vi.n_states].cpu().numpy()
+    # device tensors are in the solver's memory order; host-side results (pi.value_function) in the env's
+    V_vi = np.ascontiguousarray(vi._to_user(vi.d_value_function[:vi.n_states].cpu().numpy()))
+    P_vi = np.ascontiguousarray(vi._to_user(vi.d_policy[:vi.n_states].cpu().numpy()))
     st = pi.stats
     n, na = pi.n_states, pi.n_actions
     scale = max(1.0, float(np.abs(pi.value_function).max()))
