@@ -48,6 +48,9 @@ SIGNATURES = {
     "pi_comm_unique_id": (ctypes.c_int, [_vp]),
     "pi_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "pi_comm_init_local": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "pi_p2p_describe": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "pi_comm_init_p2p": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_char_p]),
+    "pi_p2p_compile_check": (ctypes.c_int, [ctypes.c_char_p]),
     "pi_comm_destroy": (ctypes.c_int, [_vp]),
     "pi_comm_info": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pi_allgather_V": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
@@ -80,7 +83,7 @@ SIGNATURES = {
     "pi_eval_end": (ctypes.c_int, [_vp]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 _load_error: Exception | None = None
 
@@ -145,6 +148,15 @@ def last_error() -> str:
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         raise NativeError(f"{what} failed: {last_error()}")
+
+
+def p2p_compile_check(cache_dir: Path | str | None = KERNEL_CACHE) -> None:
+    """The peer-to-peer transport's device code builds for gfx950 (needs no GPU; fills the kernel cache)."""
+    cdir = None
+    if cache_dir is not None:
+        Path(cache_dir).mkdir(parents=True, exist_ok=True)
+        cdir = str(cache_dir).encode()
+    _check(lib().pi_p2p_compile_check(cdir), "pi_p2p_compile_check")
 
 
 def comm_unique_id() -> bytes:
@@ -323,6 +335,30 @@ class Engine:
     def comm_init_local(self, rank: int, world: int, group: str) -> None:
         _check(lib().pi_comm_init_local(self._h, int(rank), int(world), group.encode()),
                "pi_comm_init_local")
+
+    P2P_DESC_BYTES = 512
+
+    def p2p_describe(self, rank: int, world: int, buffers) -> bytes:
+        """Register `buffers` — (device pointer, bytes) pairs: the arrays sends and receives will name — for the
+        peer-to-peer transport and return this rank's 512-byte descriptor (pi_p2p_describe)."""
+        n = len(buffers)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[int(p) for p, _ in buffers])
+        sizes = (ctypes.c_int64 * max(n, 1))(*[int(b) for _, b in buffers])
+        out = ctypes.create_string_buffer(self.P2P_DESC_BYTES)
+        _check(lib().pi_p2p_describe(self._h, int(rank), int(world), ptrs, sizes, n, out), "pi_p2p_describe")
+        return out.raw
+
+    def comm_init_p2p(self, rank: int, world: int, descriptors, cache_dir: Path | str | None = KERNEL_CACHE) -> None:
+        """`descriptors`: the p2p_describe results of ALL ranks, ordered by rank (pi_comm_init_p2p)."""
+        blob = b"".join(descriptors)
+        if len(blob) != self.P2P_DESC_BYTES * int(world):
+            raise NativeError(f"comm_init_p2p needs {world} descriptors of {self.P2P_DESC_BYTES} bytes")
+        cdir = None
+        if cache_dir is not None:
+            Path(cache_dir).mkdir(parents=True, exist_ok=True)
+            cdir = str(cache_dir).encode()
+        _check(lib().pi_comm_init_p2p(self._h, int(rank), int(world), ctypes.create_string_buffer(blob, len(blob)), cdir),
+               "pi_comm_init_p2p")
 
     def comm_destroy(self) -> None:
         _check(lib().pi_comm_destroy(self._h), "pi_comm_destroy")

@@ -35,20 +35,6 @@ using pi::fail;
 
 namespace pi {
 
-struct Comm {
-    int rank = 0, world = 1;
-    virtual ~Comm() {}
-    virtual const char* kind() const = 0;
-    virtual int group_begin() = 0;
-    virtual int send(const void* p, size_t bytes, int peer, hipStream_t st) = 0;
-    virtual int recv(void* p, size_t bytes, int peer, hipStream_t st) = 0;
-    virtual int group_end(hipStream_t st) = 0;
-    // every rank contributes `bytes` at full + rank * bytes; afterwards all ranks hold all
-    virtual int allgather(void* full, size_t bytes, hipStream_t st) = 0;
-    virtual int allreduce_max_f32(float* d, hipStream_t st) = 0;
-    virtual int allreduce_sum_u32(uint32_t* d, hipStream_t st) = 0;
-};
-
 struct ShardPlan {
     int64_t per = 0, s_begin = 0, s_end = 0;
     bool halo = false;
@@ -84,7 +70,20 @@ void release_comm(pi_handle* h) {
     drop_plan(h);
     delete h->comm;
     h->comm = nullptr;
+    drop_p2p_pending(h);
 }
+
+// How long a rank waits for a peer before it declares the exchange dead (seconds).  The RCCL
+// transport has its own watchdog-free wait on the GPU; what is bounded here are the HOST waits of the
+// in-process transport and the host-side polls for an asynchronous RCCL error.
+double comm_timeout_seconds() {
+    if (const char* e = std::getenv("PI_MI355_COMM_TIMEOUT")) {
+        const double v = std::atof(e);
+        if (v > 0.0) return v;
+    }
+    return 120.0;
+}
+
 
 }  // namespace pi
 
@@ -97,16 +96,7 @@ namespace {
             return fail(std::string(#expr) + ": " + ncclGetErrorString(r_));               \
     } while (0)
 
-// How long a rank waits for a peer before it declares the exchange dead (seconds).  The RCCL
-// transport has its own watchdog-free wait on the GPU; what is bounded here are the HOST waits of the
-// in-process transport and the host-side polls for an asynchronous RCCL error.
-double comm_timeout_seconds() {
-    if (const char* e = std::getenv("PI_MI355_COMM_TIMEOUT")) {
-        const double v = std::atof(e);
-        if (v > 0.0) return v;
-    }
-    return 120.0;
-}
+using pi::comm_timeout_seconds;
 
 // ---- RCCL ------------------------------------------------------------------------------
 // Failure handling ("RCCL error -> abort with message"): every RCCL call goes
@@ -238,7 +228,7 @@ struct LocalComm : pi::Comm {
         }
         return 0;
     }
-    void give_up() {
+    void give_up() override {
         std::lock_guard<std::mutex> lk(grp->mu);
         grp->failed = true;
         grp->cv.notify_all();
@@ -453,7 +443,7 @@ int pi_comm_info(pi_handle* h, int what) {
     switch (what) {
         case 0: return h->comm->rank;
         case 1: return h->comm->world;
-        case 2: return std::strcmp(h->comm->kind(), "rccl") == 0 ? 1 : 2;
+        case 2: return std::strcmp(h->comm->kind(), "rccl") == 0 ? 1 : std::strcmp(h->comm->kind(), "p2p") == 0 ? 3 : 2;
         case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
         case 4: return h->plan ? h->plan->depth : 0;
         case 5: return h->plan && h->plan->row_exact ? 1 : 0;
@@ -801,7 +791,7 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
     // must be preceded by a new communicator and a collective pi_exchange_plan (need_plan says how).  The error of the
     // failing call is kept.
     const std::string why = pi::last_error();
-    if (auto* local = dynamic_cast<LocalComm*>(h->comm)) local->give_up();   // in-process peers stop waiting at once
+    h->comm->give_up();                                                      // in-process peers stop waiting at once
     if (p->comm_stream) (void)hipStreamSynchronize(p->comm_stream);
     (void)hipStreamSynchronize(st);
     (void)hipMemsetAsync(h->d_slots, 0, 2 * pi::kSlots * sizeof(unsigned int), st);

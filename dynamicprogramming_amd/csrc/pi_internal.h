@@ -41,8 +41,26 @@ struct DeviceGuard {
     }
 };
 
-struct Comm;   // pi_comm.cpp
+// Transport of a multi-rank run (pi_comm.cpp: RCCL and the in-process test transport; pi_p2p.cpp: peer-to-peer stores
+// into IPC-mapped buffers).  send / recv between group_begin and group_end have the stream semantics of an RCCL group:
+// everything enqueued on `st` before group_end is visible to the transfer, everything enqueued after it sees the result.
+struct Comm {
+    int rank = 0, world = 1;
+    virtual ~Comm() {}
+    virtual const char* kind() const = 0;
+    virtual int group_begin() = 0;
+    virtual int send(const void* p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int recv(void* p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int group_end(hipStream_t st) = 0;
+    // every rank contributes `bytes` at full + rank * bytes; afterwards all ranks hold all
+    virtual int allgather(void* full, size_t bytes, hipStream_t st) = 0;
+    virtual int allreduce_max_f32(float* d, hipStream_t st) = 0;
+    virtual int allreduce_sum_u32(uint32_t* d, hipStream_t st) = 0;
+    // a sharded batch failed on this rank: stop peers of the same process from waiting (in-process transport)
+    virtual void give_up() {}
+};
 struct ShardPlan;
+struct P2pPending;   // pi_p2p.cpp: what pi_p2p_describe allocated for a pi_comm_init_p2p that has not happened yet
 
 struct GraphEntry {               // one captured batch of evaluation sweeps
     const void *Va = nullptr, *Vb = nullptr, *policy = nullptr, *term = nullptr, *d_delta = nullptr;
@@ -106,6 +124,7 @@ struct pi_handle {
     std::vector<int64_t> live_before;    // host: live states before each 64-state block -> list position of any state
     pi::Comm* comm = nullptr;            // multi-GPU transport (owned; pi_comm.cpp), null = single rank
     pi::ShardPlan* plan = nullptr;       // exchange plan (owned; pi_comm.cpp)
+    pi::P2pPending* p2p_pending = nullptr;   // pi_p2p_describe without its pi_comm_init_p2p yet (owned; pi_p2p.cpp)
 };
 
 namespace pi {
@@ -131,6 +150,8 @@ int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* p
                      float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);
 void drop_eval_list(pi_handle* h);     // the policy may have changed: forget the per-evaluation list
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
+void drop_p2p_pending(pi_handle* h);  // pi_p2p.cpp
+double comm_timeout_seconds();        // PI_MI355_COMM_TIMEOUT (default 120): how long a rank waits for a peer
 // hipRTC (gfx950, -O3 -ffp-contract=off) or the on-disk code-object cache -> image of one translation unit
 int compile_image(const std::string& src, const char* cache_dir, char* log, size_t log_len,
                   std::vector<char>& image, bool* cache_hit);

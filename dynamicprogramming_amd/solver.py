@@ -454,7 +454,7 @@ class _CudaPolicyIterationBase(abc.ABC):
             except Exception:  # noqa: BLE001
                 active = False
             if active and dist.get_world_size(self._process_group) > 1:
-                comm = T.NativeTransport.from_torch_distributed(self._process_group)
+                comm = T.from_environment(self._process_group)
         self._comm = comm
         self._world, self._rank = (comm.world, comm.rank) if comm is not None else (1, 0)
         self._shard_len, self._s_begin, self._s_end = T.shard_bounds(self.n_states, self._rank, self._world)

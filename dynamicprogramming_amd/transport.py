@@ -14,6 +14,11 @@ dimension 0 on 2-D grids — each peer can reach, or an all-gather of the shards
   in-process transport (``NativeTransport.local``) so that its stream ordering can be tested
   with real kernels on one GPU.
 
+* ``P2pTransport`` — the same C++ driver over the library's peer-to-peer transport (csrc/pi_p2p.cpp): halo rows are
+  stored by the sending GPU straight into the receiver's buffers (HIP IPC mappings over xGMI), hand-shaken through
+  flag pages; no RCCL communicator.  Python hands the 512-byte descriptors around (torch.distributed, any backend).
+  Chosen with ``PI_MI355_TRANSPORT=p2p`` (default ``rccl``) or by passing the transport to the solver.
+
 The CPU test-suite drives the same plan (the library's host-only ``pi_plan_segments``) from Python
 with a transport of its own (tests/dist_transport.py); it is not part of this package.
 """
@@ -102,3 +107,55 @@ class NativeTransport:
 
     def close(self) -> None:
         pass                     # the communicator dies with the engine handle
+
+
+class P2pTransport(NativeTransport):
+    """Peer-to-peer stores into IPC-mapped buffers behind the C ABI (one process per rank; csrc/pi_p2p.cpp).
+
+    The transport registers the solver's two V buffers and its policy array, so it can only be wired once they exist:
+    `attach` remembers the engine, `plan` — which the solver calls after allocating — describes, exchanges the
+    descriptors through `exchange` (a callable: bytes -> list of every rank's bytes, ordered by rank; by default
+    torch.distributed's all_gather_object on `group`) and initialises the communicator before it makes the plan."""
+
+    def __init__(self, rank: int, world: int, exchange=None, group=None):
+        super().__init__(rank, world)
+        self._exchange = exchange
+        self._group = group
+        self._connected = False
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        import torch.distributed as dist
+        return cls(dist.get_rank(group), dist.get_world_size(group), group=group)
+
+    def attach(self, solver) -> None:
+        self.engine = solver._backend.engine
+        self._stream = solver._backend._stream
+
+    def _gather(self, mine: bytes):
+        if self._exchange is not None:
+            return list(self._exchange(mine))
+        import torch.distributed as dist
+        box = [None] * self.world
+        dist.all_gather_object(box, mine, group=self._group)
+        return box
+
+    def plan(self, solver) -> None:
+        if not self._connected:
+            bufs = [(t.data_ptr(), t.numel() * t.element_size())
+                    for t in (solver.d_value_function, solver.d_new_value_function, solver.d_policy)]
+            mine = self.engine.p2p_describe(self.rank, self.world, bufs)
+            self.engine.comm_init_p2p(self.rank, self.world, self._gather(mine))
+            self._gather(b"mapped")          # nobody stores into a peer before every rank has mapped its peers
+            self._connected = True
+        super().plan(solver)
+
+
+def from_environment(group=None):
+    """The transport a sharded solver uses when it is given none: PI_MI355_TRANSPORT = rccl (default) | p2p."""
+    kind = os.environ.get("PI_MI355_TRANSPORT", "rccl").lower()
+    if kind == "p2p":
+        return P2pTransport.from_torch_distributed(group)
+    if kind != "rccl":
+        raise ValueError(f"PI_MI355_TRANSPORT={kind!r}: expected 'rccl' or 'p2p'")
+    return NativeTransport.from_torch_distributed(group)

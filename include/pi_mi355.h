@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 7
+#define PI_MI355_ABI_VERSION 8
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -220,8 +220,32 @@ int pi_comm_init(pi_handle* h, int rank, int world, const void* id128);
 /* In-process transport for tests: `world` handles of ONE process, one host thread each, exchange
  * through device-to-device copies ordered by HIP events — same stream semantics as RCCL. */
 int pi_comm_init_local(pi_handle* h, int rank, int world, const char* group_name);
+/*
+ * Peer-to-peer transport (csrc/pi_p2p.cpp): no RCCL on the data path.  The sending GPU STORES its halo rows straight
+ * into the receiving rank's buffer (mapped with hipIpcOpenMemHandle; the stores travel over xGMI) and the two sides
+ * hand-shake through counters in a small uncached flag page per rank — the rendezvous of an ncclSend / ncclRecv pair
+ * without the ~30 us group latency, which at C4 @ 8 is of the order of a rank's whole sweep; the scalar reductions go
+ * through the same pages.  One process per rank.  Everything above the transport (pi_exchange_plan,
+ * pi_eval_sweeps_sharded, the collectives below) is unchanged.  No reference counterpart
+ * (src/cuda_policy_iteration.py:300-336 is a single-device loop).
+ *   pi_p2p_describe   registers up to 4 device buffers of this rank — the ones sends and receives will name: both V
+ *                     buffers and the policy; same sizes on every rank, addresses are symmetric (offset o of buffer b
+ *                     goes to offset o of the peer's buffer b) — allocates the rank's flag page and fills a 512-byte
+ *                     descriptor (process id, device, IPC handles).  The caller all-gathers the descriptors of all ranks
+ *                     out of band, as it hands the RCCL id around (transport.py: torch.distributed over gloo);
+ *   pi_comm_init_p2p  descs = world x 512 bytes ordered by rank: maps the peers' buffers and pages, builds the transport's
+ *                     kernels (hipRTC, cache_dir as pi_compile) and installs it on the handle.  Collective in the sense
+ *                     that every rank must call it before any rank exchanges.
+ * Every device-side wait is bounded by PI_MI355_COMM_TIMEOUT seconds (default 120); a peer that never arrives is
+ * reported by the next reduction or all-gather (which therefore block on their stream), never a hung wave.
+ * pi_p2p_compile_check: the transport's device code builds for gfx950 (needs no GPU).
+ */
+int pi_p2p_describe(pi_handle* h, int rank, int world, const void* const* bufs, const int64_t* bytes, int n_bufs,
+                    void* desc512);
+int pi_comm_init_p2p(pi_handle* h, int rank, int world, const void* descs, const char* cache_dir);
+int pi_p2p_compile_check(const char* cache_dir);
 int pi_comm_destroy(pi_handle* h);
-/* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process), 3 plan (0 none, 1 all-gather, 2 halo),
+/* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process, 3 peer-to-peer), 3 plan (0 none, 1 all-gather, 2 halo),
  * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)). */
 int pi_comm_info(pi_handle* h, int what);
 

@@ -355,3 +355,45 @@ def test_register_budgets_of_the_baseline_kernels(tmp_path):
             assert usage[kernel]["vgpr"] <= limit, (name, kernel, usage[kernel])
             assert usage[kernel]["scratch"] == 0, (name, kernel, usage[kernel])
         assert usage["pi_eval_sweep_kernel"]["sgpr"] <= 80, (name, usage["pi_eval_sweep_kernel"])
+
+
+def test_p2p_transport_kernels_build_without_a_gpu_and_host_only_handles_are_refused(tmp_path):
+    """csrc/pi_p2p_kernels.hip (flag hand-shake, push, mailbox reduction) compiles for gfx950 through the library's
+    hipRTC path and lands in the code-object cache; a handle without a device cannot describe itself to peers."""
+    _native.p2p_compile_check(cache_dir=tmp_path)
+    objs = list(tmp_path.glob("pi_*.hsaco"))
+    assert len(objs) == 1 and objs[0].read_bytes()[:4] == b"\x7fELF"
+    blob = objs[0].read_bytes()
+    for kernel in (b"pi_p2p_signal_kernel", b"pi_p2p_wait_kernel", b"pi_p2p_push_kernel", b"pi_p2p_reduce_kernel"):
+        assert kernel in blob
+    eng = _host_engine("pendulum", (24, 17))
+    with pytest.raises(_native.NativeError, match="host-only handle"):
+        eng.p2p_describe(0, 2, [(4096, 64)])
+    with pytest.raises(_native.NativeError, match="call pi_p2p_describe first"):
+        eng.comm_init_p2p(0, 2, [b"\0" * 512] * 2)
+    with pytest.raises(_native.NativeError, match="descriptors of 512 bytes"):
+        eng.comm_init_p2p(0, 2, [b"\0" * 512])
+    eng.close()
+
+
+def test_transport_selection_from_the_environment(monkeypatch):
+    from dynamicprogramming_amd import transport as T
+
+    class FakeDist:
+        @staticmethod
+        def get_rank(group=None):
+            return 1
+
+        @staticmethod
+        def get_world_size(group=None):
+            return 4
+
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, "get_rank", FakeDist.get_rank)
+    monkeypatch.setattr(dist, "get_world_size", FakeDist.get_world_size)
+    monkeypatch.setenv("PI_MI355_TRANSPORT", "p2p")
+    t = T.from_environment()
+    assert isinstance(t, T.P2pTransport) and (t.rank, t.world) == (1, 4) and t.is_native
+    monkeypatch.setenv("PI_MI355_TRANSPORT", "smoke-signals")
+    with pytest.raises(ValueError, match="expected 'rccl' or 'p2p'"):
+        T.from_environment()

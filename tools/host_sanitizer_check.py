@@ -30,7 +30,7 @@ def host_runtime_is_clean_under_address_and_ub_sanitizers(tmp_path: Path) -> str
     cmd = [G.HIPCC, "-x", "c++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
            "-ffp-contract=off", "-std=c++17", "-Wall", "-Wextra", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
            "-D__HIP_PLATFORM_AMD__", f'-DPI_CSRC_DIR="{csrc}"', f'-DPI_INCLUDE_DIR="{ROOT / "include"}"',
-           str(csrc / "pi_api.cpp"), str(csrc / "pi_comm.cpp"), str(csrc / "pi_infer.cpp"),
+           str(csrc / "pi_api.cpp"), str(csrc / "pi_comm.cpp"), str(csrc / "pi_infer.cpp"), str(csrc / "pi_p2p.cpp"),
            str(ROOT / "tools" / "native" / "host_asan_driver.cpp"), "-o", str(exe),
            "-L/opt/rocm/lib", "-lhiprtc", "-lamdhip64", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
