@@ -13,7 +13,7 @@
 //     receiver:                               wait data[my page][sender] >= k    (then its next kernel starts with the
 //                                                                                 usual acquire and sees the rows)
 //
-// which is the rendezvous an RCCL send / recv pair performs, in four small launches per group (signal, wait, copy, wait)
+// which is the rendezvous an RCCL send / recv pair performs, in three small launches per group (signal + wait, copy, wait)
 // and two one-way flag writes of latency.  Scalar reductions (residual MAX, change-count SUM) go through the same pages
 // (pi_p2p_reduce_kernel), so a run needs no RCCL communicator at all.  Addresses are SYMMETRIC: a rank sends from
 // offset o of a registered buffer into offset o of the peer's registered buffer of the same index — what the in-place
@@ -114,7 +114,7 @@ namespace {
 struct P2pComm : pi::Comm {
     int device = -1;
     hipModule_t module = nullptr;
-    hipFunction_t f_signal = nullptr, f_wait = nullptr, f_push = nullptr, f_reduce = nullptr;
+    hipFunction_t f_sigwait = nullptr, f_push = nullptr, f_reduce = nullptr;
     char* page = nullptr;                                   // this rank's flag page (owned)
     struct Buf { char* base; size_t bytes; };
     std::vector<Buf> mine;                                  // [0] = scratch region of the page, [1 ..] = the caller's
@@ -214,17 +214,28 @@ struct P2pComm : pi::Comm {
             auto& v = o.is_send ? receivers : senders;
             if (std::find(v.begin(), v.end(), o.peer) == v.end()) v.push_back(o.peer);
         }
-        // 1. my receives of this group are posted: tell every sender its target region is free
-        if (!senders.empty()) {
-            Flags f = {};
-            for (int p : senders) {
-                f.ptr[f.n] = flag(peer_page[p], kOffAck, rank);
-                f.value[f.n++] = ++recv_n[p];
-            }
-            void* args[] = {&f};
-            if (launch(f_signal, 1, 64, args, st)) return 1;
+        uint32_t* err = error_word();
+        Flags none = {};
+        // 1. one wave: my receives of this group are posted — tell every sender its target region is free — and wait
+        //    until the receivers of my sends have said the same (the copy kernel then starts only when its targets are
+        //    free, instead of parking up to 1 024 workgroups on the CUs the interior sweep is using)
+        Flags posted = {}, acks = {}, done = {};
+        for (int p : senders) {
+            posted.ptr[posted.n] = flag(peer_page[p], kOffAck, rank);
+            posted.value[posted.n++] = ++recv_n[p];
         }
-        // 2. my sends: one kernel waits for the receivers' acks, stores every segment, raises their data counters
+        for (int p : receivers) {
+            const uint32_t k = ++sent_n[p];
+            acks.ptr[acks.n] = flag(page, kOffAck, p);
+            acks.value[acks.n++] = k;
+            done.ptr[done.n] = flag(peer_page[p], kOffData, rank);
+            done.value[done.n++] = k;
+        }
+        {
+            void* args[] = {&posted, &acks, &ticks, &err};
+            if (launch(f_sigwait, 1, 64, args, st)) return 1;
+        }
+        // 2. my sends: one kernel stores every segment into the peers' buffers and raises their data counters
         if (!receivers.empty()) {
             std::vector<Seg> segs;
             long long units = 0;
@@ -245,35 +256,21 @@ struct P2pComm : pi::Comm {
             segs.push_back({nullptr, nullptr, units});
             Seg* d_segs = nullptr;
             if (table_for(segs, vec4, &d_segs)) return 1;
-            // the acks are awaited by a one-wave kernel of their own: the copy kernel then starts only when its targets are
-            // free, instead of parking up to 1 024 workgroups on the CUs the interior sweep is using
-            Flags acks = {}, none = {}, done = {};
-            for (int p : receivers) {
-                const uint32_t k = ++sent_n[p];
-                acks.ptr[acks.n] = flag(page, kOffAck, p);
-                acks.value[acks.n++] = k;
-                done.ptr[done.n] = flag(peer_page[p], kOffData, rank);
-                done.value[done.n++] = k;
-            }
             int n_segs = (int)segs.size() - 1;
-            uint32_t* err = error_word();
             uint32_t* counter = flag(page, kOffCounter, 0);
-            void* wargs[] = {&acks, &ticks, &err};
-            if (launch(f_wait, 1, 64, wargs, st)) return 1;
             const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((units + 1023) / 1024, 1024));
             void* args[] = {&d_segs, &n_segs, &vec4, &none, &done, &ticks, &err, &counter};
             if (launch(f_push, grid, 256, args, st)) return 1;
         }
         // 3. wait for the data of my receives
         if (!senders.empty()) {
-            Flags f = {};
+            Flags data = {};
             for (int p : senders) {
-                f.ptr[f.n] = flag(page, kOffData, p);
-                f.value[f.n++] = recv_n[p];
+                data.ptr[data.n] = flag(page, kOffData, p);
+                data.value[data.n++] = recv_n[p];
             }
-            uint32_t* err = error_word();
-            void* args[] = {&f, &ticks, &err};
-            if (launch(f_wait, 1, 64, args, st)) return 1;
+            void* args[] = {&none, &data, &ticks, &err};
+            if (launch(f_sigwait, 1, 64, args, st)) return 1;
         }
         ops.clear();
         return 0;
@@ -466,8 +463,7 @@ int pi_comm_init_p2p(pi_handle* h, int rank, int world, const void* descs, const
     const std::string src = std::string("// generated by libpi_mi355 (peer-to-peer transport) for gfx950\n") + pi_embedded_p2p;
     if (pi::compile_image(src, cache_dir, nullptr, 0, image, nullptr)) return 1;
     PI_HIP(hipModuleLoadData(&c->module, image.data()));
-    PI_HIP(hipModuleGetFunction(&c->f_signal, c->module, "pi_p2p_signal_kernel"));
-    PI_HIP(hipModuleGetFunction(&c->f_wait, c->module, "pi_p2p_wait_kernel"));
+    PI_HIP(hipModuleGetFunction(&c->f_sigwait, c->module, "pi_p2p_sigwait_kernel"));
     PI_HIP(hipModuleGetFunction(&c->f_push, c->module, "pi_p2p_push_kernel"));
     PI_HIP(hipModuleGetFunction(&c->f_reduce, c->module, "pi_p2p_reduce_kernel"));
     pi::release_comm(h);

@@ -52,22 +52,23 @@ __device__ __forceinline__ bool pi_p2p_await(const unsigned int* p, unsigned int
     return true;
 }
 
-// "I have posted my receive number value[i]": tells sender i that the region it will store into is free.
-extern "C" __global__ void __launch_bounds__(64) pi_p2p_signal_kernel(PiP2pFlags f) {
-    __threadfence_system();
-    const int i = (int)threadIdx.x;
-    if (i < f.n) pi_p2p_store(f.ptr[i], f.value[i]);
-}
-
-// Wait for the data counters of the senders of this group.  error bits 0..15: which pair timed out.
+// Head of a group, one wave: first RAISE "my receive number value[i] is posted" at every sender of this group (its
+// target region is free from now on), then WAIT until every receiver of this group's sends has posted its own.  Signals
+// strictly before waits on every rank, so two ranks that send to each other cannot wait for each other.
+// Tail of a group: sig.n == 0, wait = the data counters of this group's senders.  error bits 0..15: which pair timed out.
 extern "C" __global__ void __launch_bounds__(64)
-pi_p2p_wait_kernel(PiP2pFlags f, unsigned long long ticks, unsigned int* error_word) {
+pi_p2p_sigwait_kernel(PiP2pFlags sig, PiP2pFlags wait, unsigned long long ticks, unsigned int* error_word) {
     const int i = (int)threadIdx.x;
-    if (i < f.n && !pi_p2p_await(f.ptr[i], f.value[i], ticks, error_word)) atomicOr(error_word, 1u << i);
+    if (sig.n > 0) {
+        __threadfence_system();
+        if (i < sig.n) pi_p2p_store(sig.ptr[i], sig.value[i]);
+    }
+    if (i < wait.n && !pi_p2p_await(wait.ptr[i], wait.value[i], ticks, error_word)) atomicOr(error_word, 1u << i);
     __threadfence_system();
 }
 
-// One launch per group: wait until every receiver has posted its receive (acks), copy all segments into the peers'
+// The copy of a group: (optionally wait until every receiver has posted its receive — acks; the host launches the
+// one-wave kernel above for that instead, so that this grid never parks on the CUs), copy all segments into the peers'
 // buffers, then — the LAST workgroup to finish, after a system-scope fence — raise the data counters (done).
 // `vec4` != 0: every segment is 16-byte aligned on both sides and a multiple of four floats long; units are float4.
 extern "C" __global__ void __launch_bounds__(256)

@@ -71,6 +71,8 @@ if mode == "halo":
 if mode.startswith("allgather"):
     assert os.environ.get("PI_MI355_EXCHANGE") == "allgather"
 assert (os.environ.get("PI_BENCH_MINIMAL") == "1") == (mode == "allgather-minimal")
+bonus = mode.endswith(" over p2p")                    # the best-effort rerun over the peer-to-peer transport
+assert (os.environ.get("PI_MI355_TRANSPORT") == "p2p") == bonus and (os.environ.get("PI_BENCH_BONUS") == "1") == bonus
 if what == "hang":
     time.sleep(600)
 if what.startswith("exit"):
@@ -118,6 +120,19 @@ def test_supervisors_relay_the_first_rung_when_it_works():
     obj = json.loads(line)
     assert obj["check"]["exchange"]["mode"] == "halo+overlap"
     assert [a["ok"] for a in obj["check"]["exchange"]["attempts"]] == [True]
+    # ... and the same exchange ran once more over the peer-to-peer transport, reported beside it
+    p2p = obj["check"]["exchange"]["p2p"]
+    assert p2p["ok"] is True and p2p["mode"] == "halo+overlap over p2p" and p2p["value"] == 1.0
+
+
+def test_a_failing_p2p_rerun_costs_nothing():
+    plan = [["ok", "ok"], ["ok", "ok"], ["ok", "ok"], ["ok", "ok"], ["ok", "exit7"]]     # index 4 = the p2p rerun
+    (_, rc0, out0), (_, rc1, out1) = _run_supervisors(plan)
+    assert (rc0, rc1) == (0, 0) and out1.strip() == ""
+    obj = json.loads(out0.strip().splitlines()[-1])
+    assert obj["value"] == 1.0 and [a["ok"] for a in obj["check"]["exchange"]["attempts"]] == [True]
+    p2p = obj["check"]["exchange"]["p2p"]
+    assert p2p["ok"] is False and p2p["exit_codes"][1] == 7 and "value" not in p2p
 
 
 def test_a_failing_rank_moves_every_rank_to_the_next_rung():

@@ -364,7 +364,7 @@ def test_p2p_transport_kernels_build_without_a_gpu_and_host_only_handles_are_ref
     objs = list(tmp_path.glob("pi_*.hsaco"))
     assert len(objs) == 1 and objs[0].read_bytes()[:4] == b"\x7fELF"
     blob = objs[0].read_bytes()
-    for kernel in (b"pi_p2p_signal_kernel", b"pi_p2p_wait_kernel", b"pi_p2p_push_kernel", b"pi_p2p_reduce_kernel"):
+    for kernel in (b"pi_p2p_sigwait_kernel", b"pi_p2p_push_kernel", b"pi_p2p_reduce_kernel"):
         assert kernel in blob
     eng = _host_engine("pendulum", (24, 17))
     with pytest.raises(_native.NativeError, match="host-only handle"):
