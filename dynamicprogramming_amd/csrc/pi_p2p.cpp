@@ -21,7 +21,7 @@
 //
 // Bootstrap is the caller's (like the 128-byte RCCL id): pi_p2p_describe fills a 512-byte descriptor (process id,
 // device, IPC handles of the registered buffers and of the flag page), the caller all-gathers the descriptors any way
-// it likes (torch.distributed over gloo in transport.py) and hands all of them to pi_comm_init_p2p.
+// it likes (torch.distributed.all_gather_object in transport.py) and hands all of them to pi_comm_init_p2p.
 //
 // Every device-side wait is bounded (PI_MI355_COMM_TIMEOUT): a peer that never arrives sets this rank's error word,
 // later waits return at once, and the next reduction / all-gather reports it on the host.

@@ -232,7 +232,7 @@ int pi_comm_init_local(pi_handle* h, int rank, int world, const char* group_name
  *                     buffers and the policy; same sizes on every rank, addresses are symmetric (offset o of buffer b
  *                     goes to offset o of the peer's buffer b) — allocates the rank's flag page and fills a 512-byte
  *                     descriptor (process id, device, IPC handles).  The caller all-gathers the descriptors of all ranks
- *                     out of band, as it hands the RCCL id around (transport.py: torch.distributed over gloo);
+ *                     out of band, as it hands the RCCL id around (MPI, files, a socket: 512 bytes per rank);
  *   pi_comm_init_p2p  descs = world x 512 bytes ordered by rank: maps the peers' buffers and pages, builds the transport's
  *                     kernels (hipRTC, cache_dir as pi_compile) and installs it on the handle.  Collective in the sense
  *                     that every rank must call it before any rank exchanges.
