@@ -129,6 +129,22 @@ int main(int argc, char** argv) {
         CHECK(pi_infer_create(-1, 4, lo, hi, shape, foreign, bits, 16, cache) == nullptr);
         CHECK(pi_infer_create(-1, 4, lo, hi, shape, negative, bits, 16, cache) == nullptr);
     }
+    // peer-to-peer transport: device code builds for gfx950; a host-only handle is refused by every entry point
+    {
+        CHECK(pi_p2p_compile_check(cache) == 0);
+        std::vector<int32_t> shape = {6, 5};
+        pi_handle* h = make(2, shape, 3);
+        CHECK(h != nullptr);
+        unsigned char desc[1024] = {0};
+        const void* bufs[1] = {desc};
+        const int64_t sizes[1] = {64};
+        CHECK(pi_p2p_describe(h, 0, 2, bufs, sizes, 1, desc) != 0 && std::strlen(pi_last_error()) > 0);
+        CHECK(pi_p2p_describe(nullptr, 0, 2, bufs, sizes, 1, desc) != 0);
+        CHECK(pi_comm_init_p2p(h, 0, 2, desc, cache) != 0);              // nothing was described
+        CHECK(pi_comm_init_p2p(h, 0, 2, nullptr, cache) != 0);
+        CHECK(pi_comm_info(h, 2) == -1);
+        pi_destroy(h);
+    }
     pi_destroy(nullptr);
     pi_infer_destroy(nullptr);
     std::puts("host_asan_driver: ok");
