@@ -53,7 +53,13 @@ struct ShardPlan {
     std::vector<std::pair<int64_t, int64_t>> first_exact, inner_exact;
     int32_t *d_first = nullptr, *d_inner = nullptr;
     int64_t n_first = 0, n_inner = 0;
+    // Fused exchange (transports that can_push()): entry k of the swept-first list goes to the peers named by the bits
+    // of d_first_dest[k] — bit j = push_peers[j] — stored by the swept-first kernel itself (pi_eval_push_kernel).
+    std::vector<int> push_peers, push_senders;
+    uint8_t* d_first_dest = nullptr;
+    bool push_ok = false;
     ~ShardPlan() {
+        if (d_first_dest) (void)hipFree(d_first_dest);
         if (d_first) (void)hipFree(d_first);
         if (d_inner) (void)hipFree(d_inner);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
@@ -447,6 +453,7 @@ int pi_comm_info(pi_handle* h, int what) {
         case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
         case 4: return h->plan ? h->plan->depth : 0;
         case 5: return h->plan && h->plan->row_exact ? 1 : 0;
+        case 6: return h->plan && h->plan->row_exact && h->plan->push_ok ? 1 : 0;
         default: return -1;
     }
 }
@@ -650,7 +657,40 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 PI_HIP(hipMemcpyAsync(plan->d_inner, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
                 PI_HIP(hipStreamSynchronize(st));
                 plan->row_exact = true;
+                // who reads which listed row: one byte per entry, bit j = the j-th distinct receiver (at most 8; a
+                // rank with more receivers keeps the copy kernel)
+                std::vector<uint8_t> dest(first.size(), 0);
+                std::vector<int64_t> start(exact.size() + 1, 0);
+                for (size_t i = 0; i < exact.size(); ++i) start[i + 1] = start[i] + (exact[i].second - exact[i].first);
+                bool fits = true;
+                for (const auto& sg : plan->segs) {
+                    if (sg.dst == c->rank) {
+                        if (std::find(plan->push_senders.begin(), plan->push_senders.end(), sg.src) == plan->push_senders.end())
+                            plan->push_senders.push_back(sg.src);
+                        continue;
+                    }
+                    auto it = std::find(plan->push_peers.begin(), plan->push_peers.end(), sg.dst);
+                    if (it == plan->push_peers.end()) {
+                        if (plan->push_peers.size() == 8) { fits = false; break; }
+                        plan->push_peers.push_back(sg.dst);
+                        it = plan->push_peers.end() - 1;
+                    }
+                    const uint8_t bit = (uint8_t)(1u << (it - plan->push_peers.begin()));
+                    // the range of `exact` that holds [a, b): the last one that starts at or before a
+                    size_t i = (size_t)(std::upper_bound(exact.begin(), exact.end(), std::make_pair(sg.a, INT64_MAX)) - exact.begin()) - 1;
+                    if (i >= exact.size() || sg.a < exact[i].first || sg.b > exact[i].second) { fits = false; break; }
+                    for (int64_t q = sg.a; q < sg.b; ++q) dest[(size_t)(start[i] + (q - exact[i].first))] |= bit;
+                }
+                if (fits && !dest.empty()) {
+                    PI_HIP(hipMalloc((void**)&plan->d_first_dest, dest.size()));
+                    PI_HIP(hipMemcpy(plan->d_first_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
+                    plan->push_ok = true;
+                }
             }
+        }
+        if (plan->push_ok) {
+            const char* e = std::getenv("PI_MI355_P2P_FUSED");
+            plan->push_ok = c->can_push() && !(e && std::atoi(e) == 0) && pi::ensure_push_module(h) == 0;
         }
         PI_HIP(hipStreamCreateWithFlags(&plan->comm_stream, hipStreamNonBlocking));
         PI_HIP(hipEventCreateWithFlags(&plan->ev_ready, hipEventDisableTiming));
@@ -754,7 +794,18 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
             const float* src = (k & 1) ? Vb : Va;
             float* dst = (k & 1) ? Va : Vb;
             const bool want = k == n_sweeps - 1 && d_delta != nullptr;
-            if (overlap) {
+            if (overlap && p->row_exact && term == nullptr && p->push_ok) {
+                // fused exchange, everything on this stream: the swept-first kernel stores its rows into the peers'
+                // buffers itself, one-wave kernels hand-shake in front of it and behind it
+                pi::Comm* c = h->comm;
+                float* const* table = nullptr;
+                if (c->push_begin(p->push_peers, p->push_senders, dst, &table, st)) return 1;
+                if (pi::launch_eval_push(h, src, dst, policy, p->d_first, p->d_first_dest, table, (int)p->push_peers.size(),
+                                         p->n_first, gamma, want, st)) return 1;
+                if (c->push_signal(st)) return 1;
+                if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_inner, gamma, want, st, p->d_inner)) return 1;
+                if (c->push_wait(st)) return 1;
+            } else if (overlap) {
                 if (p->row_exact && term == nullptr) {
                     if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_first, gamma, want, st, p->d_first)) return 1;
                 } else {

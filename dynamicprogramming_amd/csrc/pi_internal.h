@@ -58,6 +58,19 @@ struct Comm {
     virtual int allreduce_sum_u32(uint32_t* d, hipStream_t st) = 0;
     // a sharded batch failed on this rank: stop peers of the same process from waiting (in-process transport)
     virtual void give_up() {}
+    // Fused exchange (peer-to-peer transport only): the swept-first kernel stores its rows into the peers' buffers
+    // itself (pi_eval_push_kernel), everything on the ONE stream the sweeps run on.  Per sweep:
+    //   push_begin   "my receives are posted" to `senders`, wait for the same from `receivers` (one wave); returns the
+    //                device table of the receivers' addresses of `local_dst` (the full V' buffer being written)
+    //   <the caller launches the push kernel with that table>
+    //   push_signal  raise the receivers' data counters — the kernel boundary in front of it is the release
+    //   <the caller launches the interior>
+    //   push_wait    wait for the senders' data counters
+    // Same message numbers as send / recv groups, so fused and unfused exchanges may alternate (all ranks alike).
+    virtual bool can_push() const { return false; }
+    virtual int push_begin(const std::vector<int>&, const std::vector<int>&, float*, float* const**, hipStream_t) { return 1; }
+    virtual int push_signal(hipStream_t) { return 1; }
+    virtual int push_wait(hipStream_t) { return 1; }
 };
 struct ShardPlan;
 struct P2pPending;   // pi_p2p.cpp: what pi_p2p_describe allocated for a pi_comm_init_p2p that has not happened yet
@@ -90,6 +103,11 @@ struct pi_handle {
     float* d_tab = nullptr;
     unsigned int* d_slots = nullptr;     // 2 x kSlots accumulator words: residual bits | changed
     hipModule_t module = nullptr;
+    // second module, built on demand from the same translation unit + csrc/pi_push_kernels.hip (ensure_push_module)
+    hipModule_t module_push = nullptr;
+    hipFunction_t f_eval_push = nullptr;
+    std::string dynamics_src, cache_dir; // what pi_compile was given (for the second module)
+    bool has_cache_dir = false;
     hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr, f_resident = nullptr;
@@ -148,6 +166,12 @@ bool live_usable(const pi_handle* h, const uint8_t* term, int64_t s_begin, int64
 void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
 int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
                      float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);
+// pi_eval_push_kernel over `count` entries of `list` with their destination masks: V'(s) goes to Vnew[s] and to
+// peers[j][s] for every bit j of dest[k] (ensure_push_module builds the kernel the first time)
+int ensure_push_module(pi_handle* h);
+int launch_eval_push(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const int32_t* list,
+                     const uint8_t* dest, float* const* d_peers, int n_peers, int64_t count, float gamma, bool want_delta,
+                     hipStream_t st);
 void drop_eval_list(pi_handle* h);     // the policy may have changed: forget the per-evaluation list
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
 void drop_p2p_pending(pi_handle* h);  // pi_p2p.cpp

@@ -129,11 +129,18 @@ struct P2pComm : pi::Comm {
     std::vector<Op> ops;
     struct Table { std::vector<Seg> key; Seg* d = nullptr; int vec4 = 0; };
     std::vector<Table> tables;                              // device copies of the segment lists seen so far
+    // fused exchange: the receivers' addresses of a local buffer (device arrays of pointers), and the flags the two
+    // one-wave kernels behind the push kernel will raise / wait for
+    struct PeerTable { float* local; std::vector<int> peers; float** d = nullptr; };
+    std::vector<PeerTable> peer_tables;
+    Flags pending_done = {}, pending_data = {};
 
     ~P2pComm() override {
         pi::DeviceGuard guard(device);
         (void)hipDeviceSynchronize();
         for (auto& t : tables)
+            if (t.d) (void)hipFree(t.d);
+        for (auto& t : peer_tables)
             if (t.d) (void)hipFree(t.d);
         for (void* p : opened) (void)hipIpcCloseMemHandle(p);
         if (module) (void)hipModuleUnload(module);
@@ -274,6 +281,68 @@ struct P2pComm : pi::Comm {
         }
         ops.clear();
         return 0;
+    }
+    bool can_push() const override { return true; }
+    int push_begin(const std::vector<int>& receivers, const std::vector<int>& senders, float* local_dst,
+                   float* const** table, hipStream_t st) override {
+        if (alive()) return 1;
+        size_t off = 0;
+        const int b = locate(local_dst, 4, &off);
+        if (b < 0) return fail("p2p transport: the buffer being swept into was not registered with pi_p2p_describe");
+        PeerTable* hit = nullptr;
+        for (auto& t : peer_tables)
+            if (t.local == local_dst && t.peers == receivers) hit = &t;
+        if (!hit) {
+            PeerTable t;
+            t.local = local_dst;
+            t.peers = receivers;
+            std::vector<float*> host;
+            for (int p : receivers) {
+                if (p < 0 || p >= world || p == rank) return fail("p2p transport: bad peer");
+                host.push_back(reinterpret_cast<float*>(theirs[p][b] + off));
+            }
+            PI_HIP(hipMalloc((void**)&t.d, std::max<size_t>(host.size(), 1) * sizeof(float*)));
+            PI_HIP(hipMemcpy(t.d, host.data(), host.size() * sizeof(float*), hipMemcpyHostToDevice));
+            peer_tables.push_back(t);
+            hit = &peer_tables.back();
+        }
+        *table = hit->d;
+        Flags posted = {}, acks = {};
+        pending_done = {};
+        pending_data = {};
+        for (int p : senders) {
+            posted.ptr[posted.n] = flag(peer_page[p], kOffAck, rank);
+            posted.value[posted.n++] = ++recv_n[p];
+            pending_data.ptr[pending_data.n] = flag(page, kOffData, p);
+            pending_data.value[pending_data.n++] = recv_n[p];
+        }
+        for (int p : receivers) {
+            const uint32_t k = ++sent_n[p];
+            acks.ptr[acks.n] = flag(page, kOffAck, p);
+            acks.value[acks.n++] = k;
+            pending_done.ptr[pending_done.n] = flag(peer_page[p], kOffData, rank);
+            pending_done.value[pending_done.n++] = k;
+        }
+        if (posted.n == 0 && acks.n == 0) return 0;
+        uint32_t* err = error_word();
+        void* args[] = {&posted, &acks, &ticks, &err};
+        return launch(f_sigwait, 1, 64, args, st);
+    }
+    int push_signal(hipStream_t st) override {
+        if (alive()) return 1;
+        if (pending_done.n == 0) return 0;
+        Flags none = {};
+        uint32_t* err = error_word();
+        void* args[] = {&pending_done, &none, &ticks, &err};
+        return launch(f_sigwait, 1, 64, args, st);
+    }
+    int push_wait(hipStream_t st) override {
+        if (alive()) return 1;
+        if (pending_data.n == 0) return 0;
+        Flags none = {};
+        uint32_t* err = error_word();
+        void* args[] = {&none, &pending_data, &ticks, &err};
+        return launch(f_sigwait, 1, 64, args, st);
     }
     // Has a wait of this rank timed out?  Blocks on `st` (called where the host synchronises anyway).
     int health(hipStream_t st) {

@@ -245,8 +245,15 @@ int pi_p2p_describe(pi_handle* h, int rank, int world, const void* const* bufs, 
 int pi_comm_init_p2p(pi_handle* h, int rank, int world, const void* descs, const char* cache_dir);
 int pi_p2p_compile_check(const char* cache_dir);
 int pi_comm_destroy(pi_handle* h);
+/* Fused exchange: when the plan is row-exact (pi_comm_info(h, 5)) and the transport is the peer-to-peer one, the
+ * swept-first launch of every sharded evaluation sweep is pi_eval_push_kernel (csrc/pi_push_kernels.hip): the lane that
+ * stores V'(s) stores it into the peers that read the row as well, one-wave kernels hand-shake in front of it and behind
+ * it, everything on the caller's stream — no copy kernel, no second stream (pi_comm_info(h, 6) == 1;
+ * PI_MI355_P2P_FUSED=0 keeps the copy kernel).  The kernel lives in a second module of the handle that is built on
+ * demand from the same translation unit (pi_set_option 5 builds it ahead of time). */
 /* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process, 3 peer-to-peer), 3 plan (0 none, 1 all-gather, 2 halo),
- * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)). */
+ * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)), 5 row-exact plan (0 | 1),
+ * 6 fused exchange (0 | 1). */
 int pi_comm_info(pi_handle* h, int what);
 
 /* In-place collectives on the caller's stream: shard r of the buffer lives at r * shard_elems. */
@@ -350,7 +357,8 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
 
 /* Tuning: 0 = chunks per workgroup of the evaluation sweeps, 1 = of the improvement / value sweeps
  * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of
- * small grids in the LDS-resident kernel (0 | 1), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
+ * small grids in the LDS-resident kernel (0 | 1), 5 = build the fused swept-first kernel of the peer-to-peer exchange
+ * now (value != 0; after pi_compile; a compile check on host-only handles), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
  * digit k (base 8) of the value is the dimension — numbered as in pi_create and in step_dynamics' arguments —
  * that is stored as memory dimension k, 0 = slowest; e.g. 03120 (octal) = order (0, 2, 1, 3).  From then on
  * EVERY flat state index of this ABI (s_begin / s_end, the entries of V, policy and the mask, the indices the

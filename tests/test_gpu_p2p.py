@@ -51,10 +51,11 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         eng = s._backend.engine
         assert eng.comm_info(2) == 3, "the solver is not on the peer-to-peer transport"
         info = dict(s._comm.info)
+        row_exact, fused = eng.comm_info(5), eng.comm_info(6)     # before run(): it ends by closing the handle
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
                  sweeps=np.asarray(s.stats["sweeps_per_iter"]), mode=np.asarray(info["mode"]),
-                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(eng.comm_info(5)))
+                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(row_exact), fused=np.int64(fused))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -65,6 +66,12 @@ CASES = [
     (2, "pendulum", (41, 13), "halo", {}),
     (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {}),                       # no terminal states: row-exact lists
     (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "0"}),
+    # row-exact plan forced: the FUSED exchange (pi_eval_push_kernel stores the rows into the peers itself) ...
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "1"}),
+    (4, "double_pendulum_swingup", (40, 6, 8, 6), "halo", {"PI_MI355_ROW_EXACT": "1"}),   # C4 @ 8 in small, 4 ranks
+    (2, "pendulum", (41, 13), "halo", {"PI_MI355_ROW_EXACT": "1"}),
+    # ... and the same plan with the copy kernel on the second stream
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "1", "PI_MI355_P2P_FUSED": "0"}),
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {}),                            # terminal states, 6-D
     (4, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_OVERLAP": "0"}),
     (4, "cartpole_swingup", (18, 7, 9, 8), "allgather", {}),
@@ -92,6 +99,11 @@ def test_p2p_sharded_run_is_bit_identical_to_single_rank(world, name, shape, mod
         assert str(got["mode"]) == mode
         if mode == "halo":
             assert 0 < int(got["recv"]) < (world - 1) * -(-single.n_states // world)
+        if extra.get("PI_MI355_ROW_EXACT") == "1":
+            assert int(got["row_exact"]) == 1
+            assert int(got["fused"]) == (0 if extra.get("PI_MI355_P2P_FUSED") == "0" else 1)
+        elif extra.get("PI_MI355_ROW_EXACT") == "0" or mode != "halo":
+            assert int(got["fused"]) == 0
 
 
 def _worker_lonely(rank: int, world: int, port: int, out_dir: str) -> None:
