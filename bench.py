@@ -368,7 +368,8 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
                             bonus.update({"value": o2.get("value"), "ms_per_step": o2.get("ms_per_step"),
                                           "transport": x2.get("transport"), "bit_identical": x2.get("bit_identical"),
                                           "eval_ms_max": x2.get("eval_ms_max"), "eval_ms_min": x2.get("eval_ms_min"),
-                                          "per_rank": x2.get("per_rank"), "plan_mode": x2.get("mode")})
+                                          "per_rank": x2.get("per_rank"), "plan_mode": x2.get("mode"),
+                                          "row_exact": x2.get("row_exact"), "fused": x2.get("fused")})
                         except Exception as exc:  # noqa: BLE001 - the bonus never costs the result
                             bonus["parse_error"] = repr(exc)
                 break
@@ -808,6 +809,8 @@ def main() -> None:
         exchange["world"] = eng.comm_info(1)
         exchange["transport"] = {1: "rccl", 2: "in-process", 3: "p2p"}.get(eng.comm_info(2), "none")
         exchange["comm_rank"] = eng.comm_info(0)
+        exchange["row_exact"] = eng.comm_info(5) == 1
+        exchange["fused"] = eng.comm_info(6) == 1        # the swept-first kernel stores its rows into the peers itself
         mine = torch.tensor([eval_ms, improve_ms, float(exchange["recv_elems"]), float(exchange["send_elems"]),
                              float(states_per_launch)], dtype=torch.float64, device=_collective_device(dev))
         everyone = [torch.zeros_like(mine) for _ in range(world)]

@@ -19,6 +19,10 @@
 // offset o of a registered buffer into offset o of the peer's registered buffer of the same index — what the in-place
 // halo exchange and the in-place all-gathers of this library do.
 //
+// Fused form (row-exact plans; push_begin / push_signal / push_wait below, csrc/pi_push_kernels.hip): the swept-first
+// kernel of a sweep stores its rows into the peers itself, the copy kernel and the second stream disappear, and the same
+// counters are raised / awaited by one-wave kernels on the sweep's own stream.
+//
 // Bootstrap is the caller's (like the 128-byte RCCL id): pi_p2p_describe fills a 512-byte descriptor (process id,
 // device, IPC handles of the registered buffers and of the flag page), the caller all-gathers the descriptors any way
 // it likes (torch.distributed.all_gather_object in transport.py) and hands all of them to pi_comm_init_p2p.
