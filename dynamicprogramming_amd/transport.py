@@ -145,8 +145,16 @@ class P2pTransport(NativeTransport):
             bufs = [(t.data_ptr(), t.numel() * t.element_size())
                     for t in (solver.d_value_function, solver.d_new_value_function, solver.d_policy)]
             mine = self.engine.p2p_describe(self.rank, self.world, bufs)
-            self.engine.comm_init_p2p(self.rank, self.world, self._gather(mine))
-            self._gather(b"mapped")          # nobody stores into a peer before every rank has mapped its peers
+            everyone = self._gather(mine)
+            status = b"mapped"
+            try:
+                self.engine.comm_init_p2p(self.rank, self.world, everyone)
+            except _native.NativeError as exc:       # tell the peers instead of leaving them in the next collective
+                status = f"rank {self.rank}: {exc}".encode()
+            # nobody stores into a peer before every rank has mapped its peers — and a rank that could not map fails all
+            failed = [s.decode(errors="replace") for s in self._gather(status) if s != b"mapped"]
+            if failed:
+                raise _native.NativeError("peer-to-peer transport could not be set up: " + "; ".join(failed))
             self._connected = True
         super().plan(solver)
 

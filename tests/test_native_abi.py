@@ -397,3 +397,53 @@ def test_transport_selection_from_the_environment(monkeypatch):
     monkeypatch.setenv("PI_MI355_TRANSPORT", "smoke-signals")
     with pytest.raises(ValueError, match="expected 'rccl' or 'p2p'"):
         T.from_environment()
+
+
+def test_p2p_bootstrap_failure_reaches_every_rank():
+    """A rank that cannot map its peers says so in the second exchange of the bootstrap, and EVERY rank raises —
+    nobody is left waiting in the next collective (transport.P2pTransport.plan; fake engine, no GPU)."""
+    from dynamicprogramming_amd import transport as T
+
+    class Tensor:
+        def data_ptr(self):
+            return 4096
+
+        def numel(self):
+            return 16
+
+        def element_size(self):
+            return 4
+
+    class Solver:
+        d_value_function = d_new_value_function = d_policy = Tensor()
+
+    class Engine:
+        def __init__(self, fails):
+            self.fails = fails
+
+        def p2p_describe(self, rank, world, bufs):
+            assert len(bufs) == 3 and all(b == (4096, 64) for b in bufs)
+            return b"descriptor of rank %d" % rank
+
+        def comm_init_p2p(self, rank, world, everyone):
+            assert everyone == [b"descriptor of rank 0", b"descriptor of rank 1"]
+            if self.fails:
+                raise _native.NativeError("hipIpcOpenMemHandle (rank 0, buffer 1): invalid device pointer")
+
+    def exchange_for(rank, peer_says):
+        def exchange(mine):                                  # what an all-gather over two ranks returns, ordered by rank
+            theirs = peer_says.pop(0)
+            return [mine, theirs] if rank == 0 else [theirs, mine]
+        return exchange
+
+    # rank 1 fails: it raises, and rank 0 — whose own mapping worked — raises as well, naming rank 1
+    t1 = T.P2pTransport(1, 2, exchange=exchange_for(1, [b"descriptor of rank 0", b"mapped"]))
+    t1.engine = Engine(fails=True)
+    with pytest.raises(_native.NativeError, match="rank 1: hipIpcOpenMemHandle"):
+        t1.plan(Solver())
+    t0 = T.P2pTransport(0, 2, exchange=exchange_for(0, [b"descriptor of rank 1",
+                                                        b"rank 1: hipIpcOpenMemHandle (rank 0, buffer 1): invalid device pointer"]))
+    t0.engine = Engine(fails=False)
+    with pytest.raises(_native.NativeError, match="could not be set up: rank 1"):
+        t0.plan(Solver())
+    assert not t0._connected and not t1._connected
