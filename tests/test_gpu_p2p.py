@@ -43,7 +43,9 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
     from dynamicprogramming_amd.solver import CudaPIConfig
     from tests import helpers as H
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))       # a rank that dies fails its peers, in time
     try:
         cls = envs.ENVS[name]
         s = cls(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw), device="cuda:0")
@@ -118,7 +120,9 @@ def _worker_lonely(rank: int, world: int, port: int, out_dir: str) -> None:
     from dynamicprogramming_amd import _native, envs
     from dynamicprogramming_amd.solver import CudaPIConfig
     from tests import helpers as H
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))
     try:
         name, shape = "cartpole_swingup", (18, 7, 9, 8)
         cls = envs.ENVS[name]
