@@ -58,7 +58,16 @@ struct ShardPlan {
     std::vector<int> push_peers, push_senders;
     uint8_t* d_first_dest = nullptr;
     bool push_ok = false;
+    // The same for the coarse-range plan of a grid WITH terminal states whose later sweeps of a batch run over the
+    // live-state list (pi_prepare_mask_range): one byte per entry of the shard's live span.  Valid for the list it was
+    // built from (live_list / live_count).
+    uint8_t* d_live_dest = nullptr;
+    int64_t live_dest_base = 0;
+    const int32_t* live_list = nullptr;
+    int64_t live_list_count = 0;
+    bool live_push_ok = false;
     ~ShardPlan() {
+        if (d_live_dest) (void)hipFree(d_live_dest);
         if (d_first_dest) (void)hipFree(d_first_dest);
         if (d_first) (void)hipFree(d_first);
         if (d_inner) (void)hipFree(d_inner);
@@ -453,7 +462,7 @@ int pi_comm_info(pi_handle* h, int what) {
         case 3: return h->plan ? (h->plan->halo ? 2 : 1) : 0;
         case 4: return h->plan ? h->plan->depth : 0;
         case 5: return h->plan && h->plan->row_exact ? 1 : 0;
-        case 6: return h->plan && h->plan->row_exact && h->plan->push_ok ? 1 : 0;
+        case 6: return h->plan && ((h->plan->row_exact && h->plan->push_ok) || h->plan->live_push_ok) ? 1 : 0;
         default: return -1;
     }
 }
@@ -688,9 +697,44 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 }
             }
         }
-        if (plan->push_ok) {
-            const char* e = std::getenv("PI_MI355_P2P_FUSED");
-            plan->push_ok = c->can_push() && !(e && std::atoi(e) == 0) && pi::ensure_push_module(h) == 0;
+        const char* fused_env = std::getenv("PI_MI355_P2P_FUSED");
+        const bool fused_wanted = c->can_push() && !(fused_env && std::atoi(fused_env) == 0);
+        if (plan->push_ok) plan->push_ok = fused_wanted && pi::ensure_push_module(h) == 0;
+        if (!plan->row_exact && fused_wanted && pi::live_usable(h, term, plan->s_begin, plan->s_end)) {
+            // later sweeps of a batch visit the shard's live states only: who reads which of them
+            int64_t base = 0, total = 0;
+            pi::live_span(h, plan->s_begin, plan->s_end, &base, &total);
+            std::vector<uint8_t> dest((size_t)total, 0);
+            bool fits = total > 0;
+            for (const auto& sg : plan->segs) {
+                if (!fits) break;
+                if (sg.dst == c->rank) {
+                    if (std::find(plan->push_senders.begin(), plan->push_senders.end(), sg.src) == plan->push_senders.end())
+                        plan->push_senders.push_back(sg.src);
+                    continue;
+                }
+                auto it = std::find(plan->push_peers.begin(), plan->push_peers.end(), sg.dst);
+                if (it == plan->push_peers.end()) {
+                    if (plan->push_peers.size() == 8) { fits = false; break; }
+                    plan->push_peers.push_back(sg.dst);
+                    it = plan->push_peers.end() - 1;
+                }
+                const uint8_t bit = (uint8_t)(1u << (it - plan->push_peers.begin()));
+                int64_t first = 0, count = 0;
+                pi::live_span(h, sg.a, sg.b, &first, &count);
+                for (int64_t k = first - base; k < first - base + count; ++k) dest[(size_t)k] |= bit;
+            }
+            if (fits && pi::ensure_push_module(h) == 0) {
+                PI_HIP(hipMalloc((void**)&plan->d_live_dest, dest.size()));
+                PI_HIP(hipMemcpy(plan->d_live_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
+                plan->live_dest_base = base;
+                plan->live_list = h->d_live;
+                plan->live_list_count = h->live_count;
+                plan->live_push_ok = true;
+            } else {
+                plan->push_peers.clear();
+                plan->push_senders.clear();
+            }
         }
         PI_HIP(hipStreamCreateWithFlags(&plan->comm_stream, hipStreamNonBlocking));
         PI_HIP(hipEventCreateWithFlags(&plan->ev_ready, hipEventDisableTiming));
@@ -804,6 +848,24 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
                                          p->n_first, gamma, want, st)) return 1;
                 if (c->push_signal(st)) return 1;
                 if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_inner, gamma, want, st, p->d_inner)) return 1;
+                if (c->push_wait(st)) return 1;
+            } else if (overlap && k >= 1 && live && p->live_push_ok && p->live_list == h->d_live &&
+                       p->live_list_count == h->live_count) {
+                // the same fused exchange for the later sweeps of a batch on a grid with terminal states: the live
+                // states of the ranges peers wait for are swept by the push kernel, which delivers them (terminal
+                // states' values never change: every rank's buffers hold them since the batch's first sweep)
+                pi::Comm* c = h->comm;
+                float* const* table = nullptr;
+                if (c->push_begin(p->push_peers, p->push_senders, dst, &table, st)) return 1;
+                for (const auto& r : p->send_ranges) {
+                    int64_t first = 0, count = 0;
+                    pi::live_span(h, r.first, r.second, &first, &count);
+                    if (pi::launch_eval_push(h, src, dst, policy, h->d_live + first, p->d_live_dest + (first - p->live_dest_base),
+                                             table, (int)p->push_peers.size(), count, gamma, want, st)) return 1;
+                }
+                if (c->push_signal(st)) return 1;
+                for (const auto& r : p->interior)
+                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 if (c->push_wait(st)) return 1;
             } else if (overlap) {
                 if (p->row_exact && term == nullptr) {

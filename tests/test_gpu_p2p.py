@@ -53,11 +53,11 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         eng = s._backend.engine
         assert eng.comm_info(2) == 3, "the solver is not on the peer-to-peer transport"
         info = dict(s._comm.info)
-        row_exact, fused = eng.comm_info(5), eng.comm_info(6)     # before run(): it ends by closing the handle
+        row_exact, fused, live = eng.comm_info(5), eng.comm_info(6), eng.info(16)   # before run(): it closes the handle
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
                  sweeps=np.asarray(s.stats["sweeps_per_iter"]), mode=np.asarray(info["mode"]),
-                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(row_exact), fused=np.int64(fused))
+                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(row_exact), fused=np.int64(fused), live=np.int64(live))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -75,6 +75,11 @@ CASES = [
     # ... and the same plan with the copy kernel on the second stream
     (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "1", "PI_MI355_P2P_FUSED": "0"}),
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {}),                            # terminal states, 6-D
+    # grids WITH terminal states whose shards keep a live-state list: the later sweeps of every batch go through the
+    # fused exchange (push kernel over the live spans of the ranges peers wait for), the first one through the copy kernel
+    (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_LIVE_MIN": "1"}),
+    (3, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_LIVE_MIN": "1"}),
+    (3, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_LIVE_MIN": "1", "PI_MI355_P2P_FUSED": "0"}),
     (4, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_OVERLAP": "0"}),
     (4, "cartpole_swingup", (18, 7, 9, 8), "allgather", {}),
     (2, "mountain_car", (23, 19), "allgather", {}),                                    # 437 states: padded tail
@@ -104,8 +109,15 @@ def test_p2p_sharded_run_is_bit_identical_to_single_rank(world, name, shape, mod
         if extra.get("PI_MI355_ROW_EXACT") == "1":
             assert int(got["row_exact"]) == 1
             assert int(got["fused"]) == (0 if extra.get("PI_MI355_P2P_FUSED") == "0" else 1)
-        elif extra.get("PI_MI355_ROW_EXACT") == "0" or mode != "halo":
+        elif extra.get("PI_MI355_LIVE_MIN") == "1":
+            # every rank decides for itself whether its shard keeps a list (>= 3 % idle lanes otherwise); ranks with and
+            # without one — fused and unfused — interoperate: same message numbers
+            assert int(got["fused"]) == (1 if int(got["live"]) > 0 and extra.get("PI_MI355_P2P_FUSED") != "0" else 0)
+        elif extra.get("PI_MI355_ROW_EXACT") == "0" or mode != "halo" or extra.get("PI_MI355_OVERLAP") == "0":
             assert int(got["fused"]) == 0
+    if extra.get("PI_MI355_LIVE_MIN") == "1":
+        lives = [int(np.load(tmp_path / f"rank{r}.npz")["live"]) for r in range(world)]
+        assert max(lives) > 0, "no shard kept a live-state list: the case does not test what it is for"
 
 
 def _worker_lonely(rank: int, world: int, port: int, out_dir: str) -> None:
