@@ -249,7 +249,8 @@ int pi_comm_destroy(pi_handle* h);
  * swept-first launch of every sharded evaluation sweep is pi_eval_push_kernel (csrc/pi_push_kernels.hip): the lane that
  * stores V'(s) stores it into the peers that read the row as well, one-wave kernels hand-shake in front of it and behind
  * it, everything on the caller's stream — no copy kernel, no second stream (pi_comm_info(h, 6) == 1;
- * PI_MI355_P2P_FUSED=0 keeps the copy kernel).  The kernel lives in a second module of the handle that is built on
+ * PI_MI355_P2P_FUSED=0 keeps the copy kernel); on grids with terminal states whose shard keeps a live-state list
+ * (pi_prepare_mask_range) the later sweeps of every batch are fused the same way.  The kernel lives in a second module of the handle that is built on
  * demand from the same translation unit (pi_set_option 5 builds it ahead of time). */
 /* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process, 3 peer-to-peer), 3 plan (0 none, 1 all-gather, 2 halo),
  * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)), 5 row-exact plan (0 | 1),
