@@ -196,3 +196,54 @@ def test_p2p_descriptor_validation(cuda_device):
     with pytest.raises(_native.NativeError, match="not one of pi_p2p_describe"):
         eng.comm_init_p2p(0, 2, [mine, b"\0" * 512])
     assert eng.comm_info(0) == -1                           # no communicator was installed by the failed attempts
+
+
+def _worker_vi(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, out_dir: str, exchange: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    os.environ.update({"PI_MI355_TRANSPORT": "p2p", "PI_MI355_COMM_TIMEOUT": "30", "PI_MI355_EXCHANGE": exchange})
+    import datetime
+    import torch.distributed as dist
+    from dynamicprogramming_amd import envs
+    from dynamicprogramming_amd.solver import CudaPIConfig
+    from tests import helpers as H
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))
+    try:
+        cls = envs.ENVS[name]
+        make = lambda: cls(H.env_bins_space(name, shape), cls.ACTIONS, CudaPIConfig(**cfg_kw), device="cuda:0")  # noqa: E731
+        s = make()
+        d1 = s.value_iteration(max_iter=31)                  # residual looked at on sweeps 0, 25 and 30
+        s.save_checkpoint(Path(out_dir) / "vi_ckpt")         # collective (all-gathers over the transport); rank 0 writes
+        dist.barrier()
+        r = make()                                           # a SECOND communicator of this process: new flag page, new maps
+        r.load_checkpoint(Path(out_dir) / "vi_ckpt")
+        d2 = r.value_iteration(max_iter=7)
+        r._pull_tensors_from_gpu()
+        np.savez(Path(out_dir) / f"vi_rank{rank}.npz", V=r.value_function, policy=r.policy,
+                 deltas=np.asarray([d1, d2], dtype=np.float64))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_p2p_sharded_value_iteration_checkpoint_and_resume(exchange, cuda_device, tmp_path):
+    """The fused max-backup sweeps with the exchange after every sweep, a collective checkpoint and
+    a resume in a second solver of the same processes — all over the peer-to-peer transport, bit-identical to one rank
+    doing 31 + 7 sweeps without a break."""
+    import torch.multiprocessing as mp
+    from dynamicprogramming_amd import envs
+    from tests import helpers as H
+    world, name, shape = 3, "cartpole", (9, 4, 7, 3)
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "theta": 1e-30}                  # never converges early: sweep counts are exact
+    mp.spawn(_worker_vi, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path), exchange), nprocs=world, join=True)
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device, transport=False)
+    d1 = single.value_iteration(max_iter=31)
+    d2 = single.value_iteration(max_iter=7)
+    single._pull_tensors_from_gpu()
+    for r in range(world):
+        got = np.load(tmp_path / f"vi_rank{r}.npz")
+        H.assert_bits_equal(got["V"], single.value_function, f"rank {r} V")
+        assert np.array_equal(got["policy"], single.policy)
+        assert got["deltas"].tolist() == [float(d1), float(d2)]
