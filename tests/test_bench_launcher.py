@@ -79,7 +79,8 @@ if what.startswith("exit"):
     sys.exit(int(what[4:]))
 if rank == 0:
     print("noise before")
-    print(json.dumps({"metric": "m", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"]),
+    print(json.dumps({"metric": "m", "value": float(os.environ.get("FAKE_P2P_VALUE", "1.0")) if bonus else 1.0,
+                      "n_gpus": int(os.environ["WORLD_SIZE"]), "ms_per_step": 2.0,
                       "check": {"exchange": {"mode": mode, "port": os.environ["MASTER_PORT"]}}}))
 '''
 
@@ -123,6 +124,24 @@ def test_supervisors_relay_the_first_rung_when_it_works():
     # ... and the same exchange ran once more over the peer-to-peer transport, reported beside it
     p2p = obj["check"]["exchange"]["p2p"]
     assert p2p["ok"] is True and p2p["mode"] == "halo+overlap over p2p" and p2p["value"] == 1.0
+
+
+def test_the_faster_transport_is_reported_and_the_other_kept_beside_it(monkeypatch):
+    monkeypatch.setenv("FAKE_P2P_VALUE", "3.5")
+    (_, rc0, out0), (_, rc1, _) = _run_supervisors([["ok", "ok"]])
+    assert (rc0, rc1) == (0, 0)
+    (line,) = out0.strip().splitlines()
+    obj = json.loads(line)
+    assert obj["value"] == 3.5 and obj["value_by_transport"] == {
+        "rccl": 1.0, "p2p": 3.5, "reported": "p2p (the faster of the two, both measured in this run)"}
+    x = obj["check"]["exchange"]
+    assert x["mode"] == "halo+overlap over p2p" and x["rccl"]["value"] == 1.0 and x["p2p"]["ok"] is True
+    assert [a["mode"] for a in x["attempts"]] == ["halo+overlap"]
+    monkeypatch.setenv("FAKE_P2P_VALUE", "0.5")
+    (_, rc0, out0), _ = _run_supervisors([["ok", "ok"]])
+    obj = json.loads(out0.strip().splitlines()[-1])
+    assert obj["value"] == 1.0 and obj["value_by_transport"]["reported"].startswith("rccl")
+    assert obj["check"]["exchange"]["p2p"]["value"] == 0.5
 
 
 def test_a_failing_p2p_rerun_costs_nothing():
