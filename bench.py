@@ -859,6 +859,8 @@ def main() -> None:
         exchange["comm_rank"] = eng.comm_info(0)
         exchange["row_exact"] = eng.comm_info(5) == 1
         exchange["fused"] = eng.comm_info(6) == 1        # the swept-first kernel stores its rows into the peers itself
+        exchange["pair_exact"] = eng.comm_info(7) == 1   # destination masks at (i_0, i_v) granularity (any memory order)
+        exchange["fused_send_elems"] = eng.comm_info(8)  # values one fused sweep delivers from this rank (-1: not fused)
         mine = torch.tensor([eval_ms, improve_ms, float(exchange["recv_elems"]), float(exchange["send_elems"]),
                              float(states_per_launch)], dtype=torch.float64, device=_collective_device(dev))
         everyone = [torch.zeros_like(mine) for _ in range(world)]

@@ -66,6 +66,8 @@ struct ShardPlan {
     const int32_t* live_list = nullptr;
     int64_t live_list_count = 0;
     bool live_push_ok = false;
+    bool pair_exact = false;            // destination masks cut down to the pairs (i_0, i_v) each peer reads
+    int64_t fused_send_elems = -1;      // (state, receiver) pairs one fused sweep delivers; -1: not a fused plan
     ~ShardPlan() {
         if (d_live_dest) (void)hipFree(d_live_dest);
         if (d_first_dest) (void)hipFree(d_first_dest);
@@ -463,6 +465,8 @@ int pi_comm_info(pi_handle* h, int what) {
         case 4: return h->plan ? h->plan->depth : 0;
         case 5: return h->plan && h->plan->row_exact ? 1 : 0;
         case 6: return h->plan && ((h->plan->row_exact && h->plan->push_ok) || h->plan->live_push_ok) ? 1 : 0;
+        case 7: return h->plan && h->plan->pair_exact ? 1 : 0;
+        case 8: return h->plan ? (int)std::min<int64_t>(h->plan->fused_send_elems, INT32_MAX) : -1;
         default: return -1;
     }
 }
@@ -626,10 +630,120 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
             pos = std::max(pos, r.second);
         }
         if (pos < plan->s_end) plan->interior.push_back({pos, plan->s_end});
+        // ---- what a transport that can deliver from inside the sweep (can_push) adds to the plan --------------------
+        const char* fused_env = std::getenv("PI_MI355_P2P_FUSED");
+        const bool fused_wanted = c->can_push() && !(fused_env && std::atoi(fused_env) == 0) && pi::ensure_push_module(h) == 0;
+        // Pair refinement.  With the velocity that moves coordinate 0 somewhere else than in memory dimension 1 (the fast
+        // single-GPU orders put it along the lanes) the rows (i0, i1) above are all reachable and the segments are whole
+        // bands of planes; the fused exchange delivers per STATE, so the destination masks below are cut down to the
+        // pairs (i_0, i_v) every peer really reads (pi_reach_pairs_kernel) — the triangle again, in any memory order.
+        // The segments stay as they are: the unfused exchanges (a batch's first sweep on grids with terminal states,
+        // value iteration, all-gathers) travel whole.  Collective: every rank takes this branch or none (same grid,
+        // same order, same transport, same environment).
+        std::vector<uint8_t> need2;
+        int64_t units = 0, gv = 1, stv = 1;
+        const int64_t st0 = n / h->shape[0];
+        {
+            const char* e = std::getenv("PI_MI355_PAIR_REACH");
+            const int v = h->D >= 2 ? h->mem_of_user[1] : 0;
+            if (fused_wanted && pi::pairs_possible(h) && v != 1 && !(e && std::atoi(e) == 0)) {
+                gv = h->shape[v];
+                for (int d = v + 1; d < h->D; ++d) stv *= h->shape[d];
+                units = (int64_t)h->shape[0] * gv;
+                const size_t words = (size_t)(units + 31) / 32;
+                uint32_t* d_bits = nullptr;
+                uint8_t* d_all = nullptr;
+                PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
+                std::vector<uint32_t> bits(words, 0u);
+                hipError_t e1 = hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st);
+                int rc = e1 == hipSuccess ? pi::reach_pairs(h, term, plan->s_begin, plan->s_end, d_bits, st) : 1;
+                if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+                (void)hipFree(d_bits);
+                if (rc) return fail("pair reach probe failed: " + pi::last_error());
+                const size_t row = (size_t)(units + 3) / 4 * 4;
+                std::vector<uint8_t> all((size_t)c->world * row, 0);
+                for (int64_t u = 0; u < units; ++u) all[(size_t)c->rank * row + (size_t)u] = (bits[(size_t)u >> 5] >> (u & 31)) & 1u;
+                PI_HIP(hipMalloc((void**)&d_all, all.size()));
+                hipError_t e2 = hipMemcpyAsync(d_all, all.data(), all.size(), hipMemcpyHostToDevice, st);
+                if (e2 == hipSuccess) rc = c->allgather(d_all, row, st);
+                if (e2 == hipSuccess && !rc) e2 = hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, st);
+                if (e2 == hipSuccess && !rc) e2 = hipStreamSynchronize(st);
+                (void)hipFree(d_all);
+                if (e2 != hipSuccess) return fail(std::string("exchange plan (pairs): ") + hipGetErrorString(e2));
+                if (rc) return 1;
+                need2.resize((size_t)c->world * (size_t)units);
+                for (int r = 0; r < c->world; ++r) std::memcpy(&need2[(size_t)r * units], &all[(size_t)r * row], (size_t)units);
+                plan->pair_exact = true;
+            }
+        }
+        auto wanted_by = [&](int dst, int64_t q) {           // does rank dst read state q at all (pair level)?
+            return need2.empty() || need2[(size_t)dst * (size_t)units + (size_t)((q / st0) * gv + (q / stv) % gv)] != 0;
+        };
+        // bit of a receiver in the destination masks: the j-th distinct one, at most 8 (more: keep the copy kernel)
+        auto peer_bit = [&](int dst, uint8_t* bit) {
+            auto it = std::find(plan->push_peers.begin(), plan->push_peers.end(), dst);
+            if (it == plan->push_peers.end()) {
+                if (plan->push_peers.size() == 8) return false;
+                plan->push_peers.push_back(dst);
+                it = plan->push_peers.end() - 1;
+            }
+            *bit = (uint8_t)(1u << (it - plan->push_peers.begin()));
+            return true;
+        };
+        auto note_sender = [&](int src) {
+            if (std::find(plan->push_senders.begin(), plan->push_senders.end(), src) == plan->push_senders.end())
+                plan->push_senders.push_back(src);
+        };
+        auto upload_lists = [&](const std::vector<int32_t>& first, const std::vector<int32_t>& inner) -> int {
+            plan->n_first = (int64_t)first.size();
+            plan->n_inner = (int64_t)inner.size();
+            PI_HIP(hipMalloc((void**)&plan->d_first, std::max<size_t>(first.size(), 1) * sizeof(int32_t)));
+            PI_HIP(hipMalloc((void**)&plan->d_inner, std::max<size_t>(inner.size(), 1) * sizeof(int32_t)));
+            PI_HIP(hipMemcpyAsync(plan->d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            PI_HIP(hipMemcpyAsync(plan->d_inner, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            PI_HIP(hipStreamSynchronize(st));
+            plan->row_exact = true;
+            return 0;
+        };
+        int want = -1;
+        if (const char* e = std::getenv("PI_MI355_ROW_EXACT")) want = std::atoi(e) != 0 ? 1 : 0;
+        if (plan->pair_exact && term == nullptr && !cuts.empty() && want != 0) {
+            // State-exact lists (grids without terminal states): swept first = the states of this shard some peer reads,
+            // each with the mask of those peers; the rest is the interior.  Only the fused exchange can deliver them.
+            const int64_t len = plan->s_end - plan->s_begin;
+            std::vector<uint8_t> mark((size_t)len, 0);
+            bool fits = true;
+            for (const auto& sg : plan->segs) {
+                if (sg.dst == c->rank) { note_sender(sg.src); continue; }
+                uint8_t bit = 0;
+                if (!peer_bit(sg.dst, &bit)) { fits = false; break; }
+                for (int64_t q = sg.a; q < sg.b; ++q)
+                    if (wanted_by(sg.dst, q)) mark[(size_t)(q - plan->s_begin)] |= bit;
+            }
+            if (fits) {
+                std::vector<int32_t> first, inner;
+                std::vector<uint8_t> dest;
+                for (int64_t q = plan->s_begin; q < plan->s_end; ++q) {
+                    const uint8_t m = mark[(size_t)(q - plan->s_begin)];
+                    if (m) { first.push_back((int32_t)q); dest.push_back(m); }
+                    else inner.push_back((int32_t)q);
+                }
+                if (!first.empty() && (int64_t)first.size() < len) {
+                    if (upload_lists(first, inner)) return 1;
+                    PI_HIP(hipMalloc((void**)&plan->d_first_dest, dest.size()));
+                    PI_HIP(hipMemcpy(plan->d_first_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
+                    plan->push_ok = true;
+                    plan->fused_send_elems = 0;
+                    for (uint8_t m : dest) plan->fused_send_elems += __builtin_popcount(m);
+                }
+            }
+            if (!plan->push_ok) { plan->push_peers.clear(); plan->push_senders.clear(); }
+        }
         // Row-exact alternative: the union of the rows that travel, nothing merged across gaps.  Taken when the grid
         // has no terminal states (the list kernel visits listed states only and copies nothing) and it moves at least a
         // quarter of the coarse swept-first states into the interior; PI_MI355_ROW_EXACT=0 / 1 forces it off / on.
-        {
+        if (!plan->row_exact) {
             std::vector<std::pair<int64_t, int64_t>> exact;
             for (const auto& r : cuts) {
                 if (!exact.empty() && r.first <= exact.back().second)
@@ -640,8 +754,6 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
             int64_t exact_states = 0, coarse_states = 0;
             for (const auto& r : exact) exact_states += r.second - r.first;
             for (const auto& r : plan->send_ranges) coarse_states += r.second - r.first;
-            int want = -1;
-            if (const char* e = std::getenv("PI_MI355_ROW_EXACT")) want = std::atoi(e) != 0 ? 1 : 0;
             const bool possible = term == nullptr && !exact.empty() && exact_states < plan->s_end - plan->s_begin;
             const bool pays = exact.size() > plan->send_ranges.size() && 4 * exact_states <= 3 * coarse_states;
             if (possible && (want == 1 || (want < 0 && pays))) {
@@ -658,33 +770,17 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 if (at < plan->s_end) plan->inner_exact.push_back({at, plan->s_end});
                 for (int64_t q = at; q < plan->s_end; ++q) inner.push_back((int32_t)q);
                 plan->first_exact = exact;
-                plan->n_first = (int64_t)first.size();
-                plan->n_inner = (int64_t)inner.size();
-                PI_HIP(hipMalloc((void**)&plan->d_first, std::max<size_t>(first.size(), 1) * sizeof(int32_t)));
-                PI_HIP(hipMalloc((void**)&plan->d_inner, std::max<size_t>(inner.size(), 1) * sizeof(int32_t)));
-                PI_HIP(hipMemcpyAsync(plan->d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                PI_HIP(hipMemcpyAsync(plan->d_inner, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                PI_HIP(hipStreamSynchronize(st));
-                plan->row_exact = true;
-                // who reads which listed row: one byte per entry, bit j = the j-th distinct receiver (at most 8; a
-                // rank with more receivers keeps the copy kernel)
+                if (upload_lists(first, inner)) return 1;
+                // who reads which listed row: one byte per entry
                 std::vector<uint8_t> dest(first.size(), 0);
                 std::vector<int64_t> start(exact.size() + 1, 0);
                 for (size_t i = 0; i < exact.size(); ++i) start[i + 1] = start[i] + (exact[i].second - exact[i].first);
-                bool fits = true;
+                bool fits = fused_wanted;
                 for (const auto& sg : plan->segs) {
-                    if (sg.dst == c->rank) {
-                        if (std::find(plan->push_senders.begin(), plan->push_senders.end(), sg.src) == plan->push_senders.end())
-                            plan->push_senders.push_back(sg.src);
-                        continue;
-                    }
-                    auto it = std::find(plan->push_peers.begin(), plan->push_peers.end(), sg.dst);
-                    if (it == plan->push_peers.end()) {
-                        if (plan->push_peers.size() == 8) { fits = false; break; }
-                        plan->push_peers.push_back(sg.dst);
-                        it = plan->push_peers.end() - 1;
-                    }
-                    const uint8_t bit = (uint8_t)(1u << (it - plan->push_peers.begin()));
+                    if (!fits) break;
+                    if (sg.dst == c->rank) { note_sender(sg.src); continue; }
+                    uint8_t bit = 0;
+                    if (!peer_bit(sg.dst, &bit)) { fits = false; break; }
                     // the range of `exact` that holds [a, b): the last one that starts at or before a
                     size_t i = (size_t)(std::upper_bound(exact.begin(), exact.end(), std::make_pair(sg.a, INT64_MAX)) - exact.begin()) - 1;
                     if (i >= exact.size() || sg.a < exact[i].first || sg.b > exact[i].second) { fits = false; break; }
@@ -694,43 +790,44 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                     PI_HIP(hipMalloc((void**)&plan->d_first_dest, dest.size()));
                     PI_HIP(hipMemcpy(plan->d_first_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
                     plan->push_ok = true;
+                } else {
+                    plan->push_peers.clear();
+                    plan->push_senders.clear();
                 }
             }
         }
-        const char* fused_env = std::getenv("PI_MI355_P2P_FUSED");
-        const bool fused_wanted = c->can_push() && !(fused_env && std::atoi(fused_env) == 0);
-        if (plan->push_ok) plan->push_ok = fused_wanted && pi::ensure_push_module(h) == 0;
         if (!plan->row_exact && fused_wanted && pi::live_usable(h, term, plan->s_begin, plan->s_end)) {
             // later sweeps of a batch visit the shard's live states only: who reads which of them
             int64_t base = 0, total = 0;
             pi::live_span(h, plan->s_begin, plan->s_end, &base, &total);
             std::vector<uint8_t> dest((size_t)total, 0);
+            std::vector<int32_t> states;
             bool fits = total > 0;
             for (const auto& sg : plan->segs) {
                 if (!fits) break;
-                if (sg.dst == c->rank) {
-                    if (std::find(plan->push_senders.begin(), plan->push_senders.end(), sg.src) == plan->push_senders.end())
-                        plan->push_senders.push_back(sg.src);
-                    continue;
-                }
-                auto it = std::find(plan->push_peers.begin(), plan->push_peers.end(), sg.dst);
-                if (it == plan->push_peers.end()) {
-                    if (plan->push_peers.size() == 8) { fits = false; break; }
-                    plan->push_peers.push_back(sg.dst);
-                    it = plan->push_peers.end() - 1;
-                }
-                const uint8_t bit = (uint8_t)(1u << (it - plan->push_peers.begin()));
+                if (sg.dst == c->rank) { note_sender(sg.src); continue; }
+                uint8_t bit = 0;
+                if (!peer_bit(sg.dst, &bit)) { fits = false; break; }
                 int64_t first = 0, count = 0;
                 pi::live_span(h, sg.a, sg.b, &first, &count);
-                for (int64_t k = first - base; k < first - base + count; ++k) dest[(size_t)k] |= bit;
+                if (need2.empty()) {
+                    for (int64_t k = first - base; k < first - base + count; ++k) dest[(size_t)k] |= bit;
+                } else {
+                    states.clear();
+                    pi::live_states(h, sg.a, sg.b, states);              // the listed states of [a, b), ascending
+                    for (int64_t k = 0; k < count; ++k)
+                        if (wanted_by(sg.dst, states[(size_t)k])) dest[(size_t)(first - base + k)] |= bit;
+                }
             }
-            if (fits && pi::ensure_push_module(h) == 0) {
+            if (fits) {
                 PI_HIP(hipMalloc((void**)&plan->d_live_dest, dest.size()));
                 PI_HIP(hipMemcpy(plan->d_live_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
                 plan->live_dest_base = base;
                 plan->live_list = h->d_live;
                 plan->live_list_count = h->live_count;
                 plan->live_push_ok = true;
+                plan->fused_send_elems = 0;
+                for (uint8_t m : dest) plan->fused_send_elems += __builtin_popcount(m);
             } else {
                 plan->push_peers.clear();
                 plan->push_senders.clear();
@@ -763,7 +860,7 @@ int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap) {
     if (need_plan(h)) return -1;
     const pi::ShardPlan* p = h->plan;
     std::vector<std::array<int64_t, 3>> all;
-    if (p->halo && p->comm_stream != nullptr && p->row_exact) {
+    if (p->halo && p->comm_stream != nullptr && p->row_exact && !p->first_exact.empty()) {
         for (const auto& r : p->first_exact) all.push_back({0, r.first, r.second});
         for (const auto& r : p->inner_exact) all.push_back({1, r.first, r.second});
     } else if (p->halo && p->comm_stream != nullptr) {

@@ -105,7 +105,7 @@ struct pi_handle {
     hipModule_t module = nullptr;
     // second module, built on demand from the same translation unit + csrc/pi_push_kernels.hip (ensure_push_module)
     hipModule_t module_push = nullptr;
-    hipFunction_t f_eval_push = nullptr;
+    hipFunction_t f_eval_push = nullptr, f_reach_pairs = nullptr;
     std::string dynamics_src, cache_dir; // what pi_compile was given (for the second module)
     bool has_cache_dir = false;
     hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
@@ -164,6 +164,7 @@ int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
 // over `count` list entries from position `first` — for sweeps that need not copy terminal values.
 bool live_usable(const pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end);
 void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
+void live_states(const pi_handle* h, int64_t s_begin, int64_t s_end, std::vector<int32_t>& out);   // appends, ascending
 int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
                      float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);
 // pi_eval_push_kernel over `count` entries of `list` with their destination masks: V'(s) goes to Vnew[s] and to
@@ -172,6 +173,10 @@ int ensure_push_module(pi_handle* h);
 int launch_eval_push(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, const int32_t* list,
                      const uint8_t* dest, float* const* d_peers, int n_peers, int64_t count, float gamma, bool want_delta,
                      hipStream_t st);
+// Reach of [s_begin, s_end) under all actions in pairs (i_0, i_v), v = the memory dimension of the user's dimension 1:
+// bit i_0 * g_v + i_v of d_bitmap (zeroed by the caller; g_0 * g_v bits).  Second module; 3-D and up, g_0 * g_v <= 2^17.
+bool pairs_possible(const pi_handle* h);
+int reach_pairs(pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end, uint32_t* d_bitmap, hipStream_t st);
 void drop_eval_list(pi_handle* h);     // the policy may have changed: forget the per-evaluation list
 void release_comm(pi_handle* h);      // pi_comm.cpp: tears down the transport and the exchange plan
 void drop_p2p_pending(pi_handle* h);  // pi_p2p.cpp

@@ -88,3 +88,60 @@ pi_eval_push_kernel(const float* __restrict__ V, float* __restrict__ Vn, const i
     }
     if (delta_bits != nullptr) pi_wave_max_to<PI_BLOCK_EVAL>(dmax, delta_bits);
 }
+
+// ---- reach of a state range at (dimension 0, coupled velocity) granularity, in ANY memory order ---------------------
+// The halo of a shard along dimension 0 is a triangle in (i_0, i_v) — v the velocity that moves coordinate 0
+// (x' = x + dt x_dot: the USER's dimension 1 in every reference env) — because only states that are fast enough reach
+// the neighbouring planes.  pi_reach_units_kernel measures it in rows (i_0, i_1) of the MEMORY order, which are the
+// same sets only while the velocity is the second-slowest dimension — the env's own order.  With the velocity anywhere
+// else (the fast single-GPU orders put it along the lanes: DESIGN.md section 3) those rows are all reachable and the
+// halo doubles.  The fused exchange does not need contiguous rows — every state carries its own destination mask —
+// so this probe measures the pairs (i_0, i_v) themselves, v = PI_MEM_OF[1]: bit i_0 * g_v + i_v of `bitmap` is set
+// when some state of [s_begin, s_end) under some action reads a corner with those two indices.
+constexpr int PI_PAIR_DIM = PI_D >= 2 ? PI_MEM_OF[1] : 0;
+constexpr int PI_PAIR_UNITS = PI_GRID.g[0] * (PI_D >= 2 ? PI_GRID.g[PI_PAIR_DIM] : 1);
+#define PI_PAIR_WORDS ((PI_PAIR_UNITS + 31) / 32)
+#if PI_D >= 3
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_reach_pairs_kernel(const unsigned char* __restrict__ term, const float* __restrict__ tab, long long s_begin,
+                      long long s_end, unsigned int* __restrict__ bitmap, int cpw) {
+    // the host launches this only when g_0 * g_v <= 2^17 (16 KB of bits); bigger grids keep the row-level plan
+    constexpr bool kFits = PI_PAIR_UNITS <= (1 << 17);
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ unsigned int lds_bits[kFits ? PI_PAIR_WORDS : 1];
+    if (!kFits) return;
+    long long chunk0, n_chunks;
+    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
+    const long long chunk_end = min(chunk0 + cpw, n_chunks);
+    pi_stage_table<PI_BLOCK>(tab, lds_tab);
+    for (int i = threadIdx.x; i < PI_PAIR_WORDS; i += PI_BLOCK) lds_bits[i] = 0u;
+    __syncthreads();
+    constexpr unsigned int gv = PI_GRID.g[PI_PAIR_DIM];
+    constexpr unsigned int st0 = PI_GRID.stride[0], stv = PI_GRID.stride[PI_PAIR_DIM];
+    for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {
+        const long long s = s_begin + chunk * PI_BLOCK + threadIdx.x;
+        if (s >= s_end || (term != nullptr && term[s])) continue;
+        float x[PI_D];
+        pi_state_coords((unsigned int)s, lds_tab, x);
+        int last = -1;
+        for (int a = 0; a < PI_NA; ++a) {
+            float ns[PI_D], reward, fr[PI_D];
+            bool done;
+            pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &reward, &done);
+            if (done) continue;
+            unsigned int base;
+            pi_locate(ns, base, fr);
+            const int u = (int)((base / st0) * gv + (base / stv) % gv);
+            if (u == last) continue;
+            last = u;
+            atomicOr(&lds_bits[u >> 5], 1u << (u & 31));                      // the cell's four corners in (i_0, i_v)
+            atomicOr(&lds_bits[(u + 1) >> 5], 1u << ((u + 1) & 31));
+            atomicOr(&lds_bits[(u + (int)gv) >> 5], 1u << ((u + (int)gv) & 31));
+            atomicOr(&lds_bits[(u + (int)gv + 1) >> 5], 1u << ((u + (int)gv + 1) & 31));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PI_PAIR_WORDS; i += PI_BLOCK)
+        if (lds_bits[i] != 0u) atomicOr(&bitmap[i], lds_bits[i]);
+}
+#endif

@@ -255,6 +255,7 @@ class DoublePendulumSwingUpCuda(CudaPolicyIteration4D):
     # device memory order (theta1, theta2, th1_dot, th2_dot): 80^4 evaluation sweep 0.399 -> 0.372 ms on MI355X
     # (tools/dim_order_sweep.py, profiles/r04/dim_order.txt); big grids only (solver._ORDER_MIN_STATES)
     MEMORY_ORDER = (0, 2, 1, 3)
+    SHARDED_MEMORY_ORDER = (0, 2, 1, 3)      # theta1 stays slowest: the same order serves the sharded fused exchange
     ACTIONS = np.array([-3.0, -1.5, -0.5, -0.15, -0.05, 0.0, 0.05, 0.15, 0.5, 1.5, 3.0],
                        dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=15_000, max_pi_iter=300, log_interval=500)
@@ -481,6 +482,7 @@ class DoubleCartPoleCuda(CudaPolicyIteration6D):
     # 3.68 -> 2.87 ms, improvement 7.19 -> 6.88 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt; with x kept
     # slowest, (0, 2, 3, 5, 4, 1): 3.07 / 7.11).  Single-rank solvers only: sharded ones keep the env's order.
     MEMORY_ORDER = (5, 4, 2, 3, 0, 1)
+    SHARDED_MEMORY_ORDER = (0, 2, 3, 5, 4, 1)   # x slowest (shards), x_dot along the lanes: solver.SHARDED_MEMORY_ORDER
     ACTIONS = np.array([-10.0, 0.0, 10.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=10_000, max_pi_iter=200, log_interval=500)
     _TH_FAIL = 20.0 * np.pi / 180.0
@@ -534,6 +536,7 @@ class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
     # evaluation sweep 7.84 -> 5.16 ms, improvement 35.2 -> 24.3 ms (tools/dim_order_sweep.py, profiles/r04/dim_order.txt;
     # with x kept slowest, (0, 4, 5, 2, 3, 1): 5.38 / 28.9).  Single-rank solvers only: sharded ones keep the env's order.
     MEMORY_ORDER = (4, 5, 2, 3, 0, 1)
+    SHARDED_MEMORY_ORDER = (0, 4, 5, 2, 3, 1)   # x slowest (shards), x_dot along the lanes
     ACTIONS = np.array([-60.0, -30.0, -10.0, -3.0, 0.0, 3.0, 10.0, 30.0, 60.0], dtype=np.float32)
     CONFIG = dict(gamma=0.999, theta=1e-4, max_eval_iter=20_000, max_pi_iter=300, log_interval=500)
 

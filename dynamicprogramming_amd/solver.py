@@ -185,6 +185,11 @@ class _CudaPolicyIterationBase(abc.ABC):
     # (value_function, policy, states_space, archives, checkpoints) are always in the user's order; the device
     # tensors (d_value_function, d_policy, d_terminal_mask) are in memory order.
     MEMORY_ORDER = None
+    # The order of a SHARDED solver whose transport delivers per state (the peer-to-peer transport's fused exchange):
+    # dimension 0 stays slowest — shards are slabs along it — everything else may move, the velocity that couples
+    # neighbouring planes included, because the halo is then measured in pairs (i_0, i_v) wherever v lies in memory
+    # (csrc/pi_push_kernels.hip: pi_reach_pairs_kernel).  None: the env's own order (what RCCL-sharded solvers keep).
+    SHARDED_MEMORY_ORDER = None
     _ORDER_MIN_STATES = 1 << 22
     # Sweep backend class.  Private: the product has exactly one (the HIP backend); the CPU test-suite
     # swaps a checker in here to exercise the host logic without a GPU (tests/helpers.py).
@@ -256,6 +261,16 @@ class _CudaPolicyIterationBase(abc.ABC):
         except Exception:  # noqa: BLE001
             return False
 
+    def _shards_over_p2p(self) -> bool:
+        """Whether the multi-rank transport of this solver will be the peer-to-peer one (decided as _init_sharding
+        decides it): the only one that can deliver a halo that is not made of contiguous rows."""
+        import os
+        comm = self._transport_arg
+        if comm is not None and comm is not False:
+            from . import transport as T
+            return isinstance(comm, T.P2pTransport)
+        return os.environ.get("PI_MI355_TRANSPORT", "rccl").lower() == "p2p" and os.environ.get("PI_MI355_P2P_FUSED", "1") != "0"
+
     def _choose_memory_order(self):
         """The class's MEMORY_ORDER on big single-rank grids; the env's own order otherwise.  Sharded solvers keep the
         env's order by default: the orders that are fastest on one GPU move the velocity that couples neighbouring planes
@@ -273,6 +288,9 @@ class _CudaPolicyIterationBase(abc.ABC):
             order = tuple(int(v) for v in env.split(","))
         elif self.MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES and not self._will_shard():
             order = tuple(self.MEMORY_ORDER)
+        elif (self.SHARDED_MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES and self._will_shard()
+              and self._shards_over_p2p()):
+            order = tuple(self.SHARDED_MEMORY_ORDER)
         else:
             return None
         if sorted(order) != list(range(self._D)):

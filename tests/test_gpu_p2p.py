@@ -53,11 +53,12 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         eng = s._backend.engine
         assert eng.comm_info(2) == 3, "the solver is not on the peer-to-peer transport"
         info = dict(s._comm.info)
-        row_exact, fused, live = eng.comm_info(5), eng.comm_info(6), eng.info(16)   # before run(): it closes the handle
+        row_exact, fused, live, pairs = eng.comm_info(5), eng.comm_info(6), eng.info(16), eng.comm_info(7)   # before run()
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
                  sweeps=np.asarray(s.stats["sweeps_per_iter"]), mode=np.asarray(info["mode"]),
-                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(row_exact), fused=np.int64(fused), live=np.int64(live))
+                 recv=np.int64(info["recv_elems"]), row_exact=np.int64(row_exact), fused=np.int64(fused), live=np.int64(live), pairs=np.int64(pairs),
+                 send=np.int64(info["send_elems"]), order=np.asarray(eng.order))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -75,6 +76,14 @@ CASES = [
     # ... and the same plan with the copy kernel on the second stream
     (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "1", "PI_MI355_P2P_FUSED": "0"}),
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {}),                            # terminal states, 6-D
+    # the velocity that couples neighbouring planes moved out of memory dimension 1 (what the fast single-GPU orders do):
+    # rows (i0, i1) are then all reachable, and the fused exchange cuts its destination masks down to the pairs
+    # (i_0, i_v) each peer really reads (pi_reach_pairs_kernel) — state-exact lists, delivered per state
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ORDER": "0,2,1,3"}),
+    (4, "double_pendulum_swingup", (40, 6, 8, 6), "halo", {"PI_MI355_ORDER": "0,2,3,1"}),
+    (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1"}),
+    (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1",
+                                                       "PI_MI355_PAIR_REACH": "0"}),
     # grids WITH terminal states whose shards keep a live-state list: the later sweeps of every batch go through the
     # fused exchange (push kernel over the live spans of the ranges peers wait for), the first one through the copy kernel
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_LIVE_MIN": "1"}),
@@ -106,7 +115,12 @@ def test_p2p_sharded_run_is_bit_identical_to_single_rank(world, name, shape, mod
         assert str(got["mode"]) == mode
         if mode == "halo":
             assert 0 < int(got["recv"]) < (world - 1) * -(-single.n_states // world)
-        if extra.get("PI_MI355_ROW_EXACT") == "1":
+        if "PI_MI355_ORDER" in extra:
+            assert got["order"].tolist() == [int(v) for v in extra["PI_MI355_ORDER"].split(",")]
+            assert int(got["pairs"]) == (0 if extra.get("PI_MI355_PAIR_REACH") == "0" else 1)
+            if "PI_MI355_LIVE_MIN" not in extra:
+                assert int(got["row_exact"]) == 1 and int(got["fused"]) == 1      # state-exact lists, fused
+        elif extra.get("PI_MI355_ROW_EXACT") == "1":
             assert int(got["row_exact"]) == 1
             assert int(got["fused"]) == (0 if extra.get("PI_MI355_P2P_FUSED") == "0" else 1)
         elif extra.get("PI_MI355_LIVE_MIN") == "1":
