@@ -66,6 +66,7 @@ struct ShardPlan {
     const int32_t* live_list = nullptr;
     int64_t live_list_count = 0;
     bool live_push_ok = false;
+    bool live_exact = false;            // d_first / d_inner / d_first_dest hold the split of the shard's LIVE states
     bool pair_exact = false;            // destination masks cut down to the pairs (i_0, i_v) each peer reads
     int64_t fused_send_elems = -1;      // (state, receiver) pairs one fused sweep delivers; -1: not a fused plan
     ~ShardPlan() {
@@ -820,14 +821,38 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 }
             }
             if (fits) {
-                PI_HIP(hipMalloc((void**)&plan->d_live_dest, dest.size()));
-                PI_HIP(hipMemcpy(plan->d_live_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
-                plan->live_dest_base = base;
                 plan->live_list = h->d_live;
                 plan->live_list_count = h->live_count;
                 plan->live_push_ok = true;
                 plan->fused_send_elems = 0;
                 for (uint8_t m : dest) plan->fused_send_elems += __builtin_popcount(m);
+                // State-exact lists for these sweeps too: swept first = the live states some peer reads (with their
+                // masks), interior = the shard's other live states — instead of the coarse ranges, which in the orders
+                // that keep the coupling velocity off memory dimension 1 are whole bands of planes.
+                std::vector<int32_t> every, first, inner;
+                std::vector<uint8_t> dfirst;
+                pi::live_states(h, plan->s_begin, plan->s_end, every);
+                if ((int64_t)every.size() == total) {
+                    for (int64_t k = 0; k < total; ++k) {
+                        if (dest[(size_t)k]) { first.push_back(every[(size_t)k]); dfirst.push_back(dest[(size_t)k]); }
+                        else inner.push_back(every[(size_t)k]);
+                    }
+                }
+                if (!first.empty() && !inner.empty()) {
+                    plan->n_first = (int64_t)first.size();
+                    plan->n_inner = (int64_t)inner.size();
+                    PI_HIP(hipMalloc((void**)&plan->d_first, first.size() * sizeof(int32_t)));
+                    PI_HIP(hipMalloc((void**)&plan->d_inner, inner.size() * sizeof(int32_t)));
+                    PI_HIP(hipMalloc((void**)&plan->d_first_dest, dfirst.size()));
+                    PI_HIP(hipMemcpy(plan->d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    PI_HIP(hipMemcpy(plan->d_inner, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    PI_HIP(hipMemcpy(plan->d_first_dest, dfirst.data(), dfirst.size(), hipMemcpyHostToDevice));
+                    plan->live_exact = true;
+                } else {
+                    PI_HIP(hipMalloc((void**)&plan->d_live_dest, dest.size()));
+                    PI_HIP(hipMemcpy(plan->d_live_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
+                    plan->live_dest_base = base;
+                }
             } else {
                 plan->push_peers.clear();
                 plan->push_senders.clear();
@@ -954,15 +979,22 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
                 pi::Comm* c = h->comm;
                 float* const* table = nullptr;
                 if (c->push_begin(p->push_peers, p->push_senders, dst, &table, st)) return 1;
-                for (const auto& r : p->send_ranges) {
-                    int64_t first = 0, count = 0;
-                    pi::live_span(h, r.first, r.second, &first, &count);
-                    if (pi::launch_eval_push(h, src, dst, policy, h->d_live + first, p->d_live_dest + (first - p->live_dest_base),
-                                             table, (int)p->push_peers.size(), count, gamma, want, st)) return 1;
+                if (p->live_exact) {
+                    if (pi::launch_eval_push(h, src, dst, policy, p->d_first, p->d_first_dest, table, (int)p->push_peers.size(),
+                                             p->n_first, gamma, want, st)) return 1;
+                    if (c->push_signal(st)) return 1;
+                    if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_inner, gamma, want, st, p->d_inner)) return 1;
+                } else {
+                    for (const auto& r : p->send_ranges) {
+                        int64_t first = 0, count = 0;
+                        pi::live_span(h, r.first, r.second, &first, &count);
+                        if (pi::launch_eval_push(h, src, dst, policy, h->d_live + first, p->d_live_dest + (first - p->live_dest_base),
+                                                 table, (int)p->push_peers.size(), count, gamma, want, st)) return 1;
+                    }
+                    if (c->push_signal(st)) return 1;
+                    for (const auto& r : p->interior)
+                        if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 }
-                if (c->push_signal(st)) return 1;
-                for (const auto& r : p->interior)
-                    if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 if (c->push_wait(st)) return 1;
             } else if (overlap) {
                 if (p->row_exact && term == nullptr) {
