@@ -429,6 +429,11 @@ class _CudaPolicyIterationBase(abc.ABC):
         # only — the states its launches visit)
         if self._term_arg is not None and hasattr(self._backend, "prepare_mask"):
             if self._comm is not None:
+                import os
+                if getattr(self._comm, "delivers_per_state", False) and os.environ.get("PI_MI355_P2P_FUSED", "1") != "0":
+                    # the fused exchange of a grid with terminal states delivers from the list sweeps: keep the list
+                    # even where it fills no idle lanes
+                    self._backend.engine.set_option(6, 1)
                 self._backend.prepare_mask(self._term_arg, self._s_begin, self._s_end)
             else:
                 self._backend.prepare_mask(self._term_arg)

@@ -117,6 +117,8 @@ class P2pTransport(NativeTransport):
     descriptors through `exchange` (a callable: bytes -> list of every rank's bytes, ordered by rank; by default
     torch.distributed's all_gather_object on `group`) and initialises the communicator before it makes the plan."""
 
+    delivers_per_state = True          # fused exchange: the sweeps store their rows into the peers themselves
+
     def __init__(self, rank: int, world: int, exchange=None, group=None):
         super().__init__(rank, world)
         self._exchange = exchange

@@ -360,7 +360,8 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
 /* Tuning: 0 = chunks per workgroup of the evaluation sweeps, 1 = of the improvement / value sweeps
  * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of
  * small grids in the LDS-resident kernel (0 | 1), 5 = build the fused swept-first kernel of the peer-to-peer exchange
- * now (value != 0; after pi_compile; a compile check on host-only handles), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
+ * now (value != 0; after pi_compile; a compile check on host-only handles), 6 = keep the live-state list of
+ * pi_prepare_mask even when it fills no idle lanes (0 | 1; the fused exchange of a sharded run delivers from the list sweeps), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
  * digit k (base 8) of the value is the dimension — numbered as in pi_create and in step_dynamics' arguments —
  * that is stored as memory dimension k, 0 = slowest; e.g. 03120 (octal) = order (0, 2, 1, 3).  From then on
  * EVERY flat state index of this ABI (s_begin / s_end, the entries of V, policy and the mask, the indices the
