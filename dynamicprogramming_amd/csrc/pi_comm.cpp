@@ -970,7 +970,7 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
                                          p->n_first, gamma, want, st)) return 1;
                 if (c->push_signal(st)) return 1;
                 if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_inner, gamma, want, st, p->d_inner)) return 1;
-                if (c->push_wait(st)) return 1;
+                if (k + 1 < n_sweeps ? c->push_wait_deferred(st) : c->push_wait(st)) return 1;     // the next sweep is fused too
             } else if (overlap && k >= 1 && live && p->live_push_ok && p->live_list == h->d_live &&
                        p->live_list_count == h->live_count) {
                 // the same fused exchange for the later sweeps of a batch on a grid with terminal states: the live
@@ -995,7 +995,7 @@ int pi_eval_sweeps_sharded(pi_handle* h, float* Va, float* Vb, const int32_t* po
                     for (const auto& r : p->interior)
                         if (sweep(src, dst, r.first, r.second, want, k)) return 1;
                 }
-                if (c->push_wait(st)) return 1;
+                if (k + 1 < n_sweeps ? c->push_wait_deferred(st) : c->push_wait(st)) return 1;     // k + 1 >= 1: fused too
             } else if (overlap) {
                 if (p->row_exact && term == nullptr) {
                     if (pi::launch_eval_live(h, src, dst, policy, 0, p->n_first, gamma, want, st, p->d_first)) return 1;

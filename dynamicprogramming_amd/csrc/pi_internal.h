@@ -65,12 +65,15 @@ struct Comm {
     //   <the caller launches the push kernel with that table>
     //   push_signal  raise the receivers' data counters — the kernel boundary in front of it is the release
     //   <the caller launches the interior>
-    //   push_wait    wait for the senders' data counters
+    //   push_wait    wait for the senders' data counters (push_wait_deferred: leave it to the next sweep's push_begin, which
+    //                then waits for both in its one launch)
     // Same message numbers as send / recv groups, so fused and unfused exchanges may alternate (all ranks alike).
     virtual bool can_push() const { return false; }
     virtual int push_begin(const std::vector<int>&, const std::vector<int>&, float*, float* const**, hipStream_t) { return 1; }
     virtual int push_signal(hipStream_t) { return 1; }
     virtual int push_wait(hipStream_t) { return 1; }
+    // instead of push_wait when the very next call on the stream is the push_begin of another fused sweep
+    virtual int push_wait_deferred(hipStream_t st) { return push_wait(st); }
 };
 struct ShardPlan;
 struct P2pPending;   // pi_p2p.cpp: what pi_p2p_describe allocated for a pi_comm_init_p2p that has not happened yet

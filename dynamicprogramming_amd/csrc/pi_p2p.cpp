@@ -137,7 +137,7 @@ struct P2pComm : pi::Comm {
     // one-wave kernels behind the push kernel will raise / wait for
     struct PeerTable { float* local; std::vector<int> peers; float** d = nullptr; };
     std::vector<PeerTable> peer_tables;
-    Flags pending_done = {}, pending_data = {};
+    Flags pending_done = {}, pending_data = {}, carry = {};
 
     ~P2pComm() override {
         pi::DeviceGuard guard(device);
@@ -327,10 +327,32 @@ struct P2pComm : pi::Comm {
             pending_done.ptr[pending_done.n] = flag(peer_page[p], kOffData, rank);
             pending_done.value[pending_done.n++] = k;
         }
-        if (posted.n == 0 && acks.n == 0) return 0;
+        // a push_wait the caller left pending (two fused sweeps back to back): its data counters are awaited by THIS
+        // launch together with the acks — one one-wave kernel between two sweeps instead of two
+        if (carry.n > 0 && carry.n + acks.n <= kMaxRanks) {
+            for (int i = 0; i < carry.n; ++i) {
+                acks.ptr[acks.n] = carry.ptr[i];
+                acks.value[acks.n++] = carry.value[i];
+            }
+            carry = {};
+        }
         uint32_t* err = error_word();
+        if (carry.n > 0) {                                   // did not fit: wait for it on its own, first
+            Flags none = {};
+            void* wargs[] = {&none, &carry, &ticks, &err};
+            if (launch(f_sigwait, 1, 64, wargs, st)) return 1;
+            carry = {};
+        }
+        if (posted.n == 0 && acks.n == 0) return 0;
         void* args[] = {&posted, &acks, &ticks, &err};
         return launch(f_sigwait, 1, 64, args, st);
+    }
+    // The next call on this stream is the push_begin of another fused sweep: let IT wait for this sweep's data.
+    int push_wait_deferred(hipStream_t) override {
+        if (alive()) return 1;
+        carry = pending_data;
+        pending_data = {};
+        return 0;
     }
     int push_signal(hipStream_t st) override {
         if (alive()) return 1;
