@@ -286,7 +286,9 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                      int64_t* info, void* stream);
 /* The launch ranges of the current plan: up to cap triples {kind, begin, end}, kind 0 = swept first
  * (peers wait for rows inside it), 1 = interior (swept while the halo travels).  Returns how many
- * there are (-1 without a plan).  A plan without overlap reports the shard as one kind-0 range. */
+ * there are (-1 without a plan).  A plan without overlap reports the shard as one kind-0 range; a plan whose swept-first
+ * set is a list of single states (pi_comm_info(h, 7): the fused exchange in a memory order whose rows are all reachable)
+ * reports the coarse row ranges it was cut from. */
 int64_t pi_plan_ranges(pi_handle* h, int64_t* ranges, int64_t cap);
 /*
  * One part of a sharded evaluation sweep WITHOUT the exchange, launched exactly as pi_eval_sweeps_sharded launches it:
