@@ -395,6 +395,36 @@ int post_exchange(pi_handle* h, float* full, hipStream_t st) {
     return c->group_end(st);
 }
 
+// This rank's reach bitmap (`units` bits on the device, produced by `probe`) -> one byte per unit -> every rank's, through
+// the transport: out[r * units + u] != 0 <=> rank r reads unit u.  Collective; blocks on `st` (planning is one-off).
+template <typename Probe>
+int gather_reach(pi::Comm* c, int64_t units, Probe probe, hipStream_t st, std::vector<uint8_t>& out, const char* what) {
+    const size_t words = (size_t)(units + 31) / 32;
+    uint32_t* d_bits = nullptr;
+    uint8_t* d_all = nullptr;
+    PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
+    std::vector<uint32_t> bits(words, 0u);
+    int rc = hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st) == hipSuccess ? probe(d_bits) : 1;
+    if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    (void)hipFree(d_bits);
+    if (rc) return fail(std::string(what) + ": reach probe failed: " + pi::last_error());
+    const size_t row = (size_t)(units + 3) / 4 * 4;              // padded to whole words for the transport
+    std::vector<uint8_t> all((size_t)c->world * row, 0);
+    for (int64_t u = 0; u < units; ++u) all[(size_t)c->rank * row + (size_t)u] = (bits[(size_t)u >> 5] >> (u & 31)) & 1u;
+    PI_HIP(hipMalloc((void**)&d_all, all.size()));
+    hipError_t e = hipMemcpyAsync(d_all, all.data(), all.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) rc = c->allgather(d_all, row, st);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+    (void)hipFree(d_all);
+    if (e != hipSuccess) return fail(std::string(what) + ": " + hipGetErrorString(e));
+    if (rc) return 1;
+    out.resize((size_t)c->world * (size_t)units);
+    for (int r = 0; r < c->world; ++r) std::memcpy(&out[(size_t)r * units], &all[(size_t)r * row], (size_t)units);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -559,30 +589,11 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
     plan->s_begin = std::min((int64_t)c->rank * per, n);
     plan->s_end = std::min(plan->s_begin + per, n);
     if (mode != 1) {
-        // reach bitmap of this shard -> bytes -> all ranks
-        const size_t words = (size_t)(g0 + 31) / 32;
-        uint32_t* d_bits = nullptr;
-        uint8_t* d_all = nullptr;
-        PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
-        std::vector<uint32_t> bits(words, 0u);
-        int rc = pi_reach_units(h, term, plan->s_begin, plan->s_end, depth, d_bits, stream);
-        if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
-        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
-        (void)hipFree(d_bits);
-        if (rc) return fail("reach probe failed: " + pi::last_error());
-        const size_t row = (size_t)(g0 + 3) / 4 * 4;             // padded to whole words for the transport
-        std::vector<uint8_t> all((size_t)c->world * row, 0);
-        for (int64_t p = 0; p < g0; ++p) all[(size_t)c->rank * row + p] = (bits[p >> 5] >> (p & 31)) & 1u;
-        PI_HIP(hipMalloc((void**)&d_all, all.size()));
-        hipError_t e = hipMemcpyAsync(d_all, all.data(), all.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) rc = c->allgather(d_all, row, st);
-        if (e == hipSuccess && !rc) e = hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
-        (void)hipFree(d_all);
-        if (e != hipSuccess) return fail(std::string("exchange plan: ") + hipGetErrorString(e));
-        if (rc) return 1;
-        std::vector<uint8_t> reach((size_t)c->world * g0);
-        for (int r = 0; r < c->world; ++r) std::memcpy(&reach[(size_t)r * g0], &all[(size_t)r * row], (size_t)g0);
+        // reach bitmap of this shard -> all ranks
+        std::vector<uint8_t> reach;
+        if (gather_reach(c, g0, [&](uint32_t* d_bits) { return pi_reach_units(h, term, plan->s_begin, plan->s_end, depth, d_bits, stream); },
+                         st, reach, "exchange plan"))
+            return 1;
         const int64_t count = pi_plan_segments(c->world, g0, stride0, n, per, reach.data(), nullptr, 0);
         std::vector<int64_t> segs((size_t)count * 4);
         pi_plan_segments(c->world, g0, stride0, n, per, reach.data(), segs.data(), count);
@@ -651,30 +662,9 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 gv = h->shape[v];
                 for (int d = v + 1; d < h->D; ++d) stv *= h->shape[d];
                 units = (int64_t)h->shape[0] * gv;
-                const size_t words = (size_t)(units + 31) / 32;
-                uint32_t* d_bits = nullptr;
-                uint8_t* d_all = nullptr;
-                PI_HIP(hipMalloc((void**)&d_bits, words * sizeof(uint32_t)));
-                std::vector<uint32_t> bits(words, 0u);
-                hipError_t e1 = hipMemsetAsync(d_bits, 0, words * sizeof(uint32_t), st);
-                int rc = e1 == hipSuccess ? pi::reach_pairs(h, term, plan->s_begin, plan->s_end, d_bits, st) : 1;
-                if (!rc && hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
-                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
-                (void)hipFree(d_bits);
-                if (rc) return fail("pair reach probe failed: " + pi::last_error());
-                const size_t row = (size_t)(units + 3) / 4 * 4;
-                std::vector<uint8_t> all((size_t)c->world * row, 0);
-                for (int64_t u = 0; u < units; ++u) all[(size_t)c->rank * row + (size_t)u] = (bits[(size_t)u >> 5] >> (u & 31)) & 1u;
-                PI_HIP(hipMalloc((void**)&d_all, all.size()));
-                hipError_t e2 = hipMemcpyAsync(d_all, all.data(), all.size(), hipMemcpyHostToDevice, st);
-                if (e2 == hipSuccess) rc = c->allgather(d_all, row, st);
-                if (e2 == hipSuccess && !rc) e2 = hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, st);
-                if (e2 == hipSuccess && !rc) e2 = hipStreamSynchronize(st);
-                (void)hipFree(d_all);
-                if (e2 != hipSuccess) return fail(std::string("exchange plan (pairs): ") + hipGetErrorString(e2));
-                if (rc) return 1;
-                need2.resize((size_t)c->world * (size_t)units);
-                for (int r = 0; r < c->world; ++r) std::memcpy(&need2[(size_t)r * units], &all[(size_t)r * row], (size_t)units);
+                if (gather_reach(c, units, [&](uint32_t* d_bits) { return pi::reach_pairs(h, term, plan->s_begin, plan->s_end, d_bits, st); },
+                                 st, need2, "exchange plan (pairs)"))
+                    return 1;
                 plan->pair_exact = true;
             }
         }
