@@ -395,6 +395,16 @@ int post_exchange(pi_handle* h, float* full, hipStream_t st) {
     return c->group_end(st);
 }
 
+// Fault injection for the tests (PI_MI355_DEBUG_DROP_DELIVERY=k): every k-th destination mask of a fused plan is cleared —
+// the state is still swept, its value is just not delivered — so that a test can show its poisoning check FAILS when a
+// delivery is missing (tests/test_gpu_p2p.py).  Off unless the variable is set.
+void drop_deliveries_for_tests(std::vector<uint8_t>& dest) {
+    const char* e = std::getenv("PI_MI355_DEBUG_DROP_DELIVERY");
+    const int k = e ? std::atoi(e) : 0;
+    if (k > 0)
+        for (size_t i = (size_t)k - 1; i < dest.size(); i += (size_t)k) dest[i] = 0;
+}
+
 // This rank's reach bitmap (`units` bits on the device, produced by `probe`) -> one byte per unit -> every rank's, through
 // the transport: out[r * units + u] != 0 <=> rank r reads unit u.  Collective; blocks on `st` (planning is one-off).
 template <typename Probe>
@@ -722,6 +732,7 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                 }
                 if (!first.empty() && (int64_t)first.size() < len) {
                     if (upload_lists(first, inner)) return 1;
+                    drop_deliveries_for_tests(dest);
                     PI_HIP(hipMalloc((void**)&plan->d_first_dest, dest.size()));
                     PI_HIP(hipMemcpy(plan->d_first_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
                     plan->push_ok = true;
@@ -778,6 +789,7 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                     for (int64_t q = sg.a; q < sg.b; ++q) dest[(size_t)(start[i] + (q - exact[i].first))] |= bit;
                 }
                 if (fits && !dest.empty()) {
+                    drop_deliveries_for_tests(dest);
                     PI_HIP(hipMalloc((void**)&plan->d_first_dest, dest.size()));
                     PI_HIP(hipMemcpy(plan->d_first_dest, dest.data(), dest.size(), hipMemcpyHostToDevice));
                     plan->push_ok = true;
@@ -829,6 +841,7 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
                     }
                 }
                 if (!first.empty() && !inner.empty()) {
+                    drop_deliveries_for_tests(dfirst);
                     plan->n_first = (int64_t)first.size();
                     plan->n_inner = (int64_t)inner.size();
                     PI_HIP(hipMalloc((void**)&plan->d_first, first.size() * sizeof(int32_t)));

@@ -54,6 +54,21 @@ def _worker(rank: int, world: int, port: int, name: str, shape, cfg_kw: dict, ou
         assert eng.comm_info(2) == 3, "the solver is not on the peer-to-peer transport"
         info = dict(s._comm.info)
         row_exact, fused, live, pairs = eng.comm_info(5), eng.comm_info(6), eng.info(16), eng.comm_info(7)   # before run()
+        if env.get("TEST_POISON") == "1":
+            # Everything this rank neither owns nor is DELIVERED becomes NaN: both Jacobi buffers outside its shard are
+            # poisoned, then its peers deliver the starting values it can reach (one whole-row exchange).  From here on a
+            # destination mask that misses a state some sweep reads — under any policy the run visits — puts a NaN into V
+            # and the comparison with the single-rank run fails.  (A cell's corners are delivered whatever their weights:
+            # the reach probes mark cells, not weights.)
+            nan = float("nan")
+            for buf in (s.d_value_function, s.d_new_value_function):
+                buf[: s._s_begin] = nan
+                buf[s._s_end:] = nan
+            torch.cuda.synchronize()
+            dist.barrier()                      # nobody delivers into a buffer that is still being poisoned
+            s._comm.exchange(s, s.d_value_function)
+            torch.cuda.synchronize()
+            dist.barrier()
         s.run()
         np.savez(Path(out_dir) / f"rank{rank}.npz", V=s.value_function, policy=s.policy,
                  sweeps=np.asarray(s.stats["sweeps_per_iter"]), mode=np.asarray(info["mode"]),
@@ -84,6 +99,14 @@ CASES = [
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1"}),
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1",
                                                        "PI_MI355_PAIR_REACH": "0"}),
+    # the same plans with everything a rank is not delivered POISONED (NaN): the masks are sufficient, not just plausible
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ROW_EXACT": "1", "TEST_POISON": "1"}),
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), "halo", {"PI_MI355_ORDER": "0,2,1,3", "TEST_POISON": "1"}),
+    (4, "double_pendulum_swingup", (40, 6, 8, 6), "halo", {"PI_MI355_ORDER": "0,2,3,1", "TEST_POISON": "1"}),
+    (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1",
+                                                       "TEST_POISON": "1"}),
+    (3, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_LIVE_MIN": "1", "TEST_POISON": "1"}),
+    (4, "cartpole_swingup", (18, 7, 9, 8), "halo", {"PI_MI355_OVERLAP": "0", "TEST_POISON": "1"}),     # the copy kernel
     # grids WITH terminal states whose shards keep a live-state list: the later sweeps of every batch go through the
     # fused exchange (push kernel over the live spans of the ranges peers wait for), the first one through the copy kernel
     (2, "double_cartpole", (6, 4, 5, 4, 5, 4), "halo", {"PI_MI355_LIVE_MIN": "1"}),
@@ -261,3 +284,27 @@ def test_p2p_sharded_value_iteration_checkpoint_and_resume(exchange, cuda_device
         H.assert_bits_equal(got["V"], single.value_function, f"rank {r} V")
         assert np.array_equal(got["policy"], single.policy)
         assert got["deltas"].tolist() == [float(d1), float(d2)]
+
+
+@pytest.mark.parametrize("world,name,shape,extra", [
+    (3, "double_pendulum_swingup", (14, 9, 11, 8), {"PI_MI355_ORDER": "0,2,1,3"}),
+    (2, "double_cartpole", (6, 4, 5, 4, 5, 4), {"PI_MI355_ORDER": "0,2,3,5,4,1", "PI_MI355_LIVE_MIN": "1"}),
+])
+def test_p2p_poisoning_check_fails_when_a_delivery_is_missing(world, name, shape, extra, cuda_device, tmp_path):
+    """Negative control of the TEST_POISON cases above: with every 7th destination mask cleared (fault injection in the
+    planner: the state is swept, its value is not delivered) the poisoned runs must NOT equal the single-rank run."""
+    import torch.multiprocessing as mp
+    from dynamicprogramming_amd import envs
+    from tests import helpers as H
+    cls = envs.ENVS[name]
+    cfg_kw = {**cls.CONFIG, "max_pi_iter": 3, "max_eval_iter": 60}
+    single = cls(H.env_bins_space(name, shape), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device, transport=False)
+    single.run()
+    env = {"PI_MI355_EXCHANGE": "halo", "TEST_POISON": "1", "PI_MI355_DEBUG_DROP_DELIVERY": "7", **extra}
+    mp.spawn(_worker, args=(world, _free_port(), name, shape, cfg_kw, str(tmp_path), env), nprocs=world, join=True)
+    differs = False
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert int(got["fused"]) == 1
+        differs |= not np.array_equal(got["V"].view(np.uint32), single.value_function.view(np.uint32))
+    assert differs, "values were dropped from the deliveries and nothing noticed: the poisoning check checks nothing"
