@@ -447,3 +447,52 @@ def test_p2p_bootstrap_failure_reaches_every_rank():
     with pytest.raises(_native.NativeError, match="could not be set up: rank 1"):
         t0.plan(Solver())
     assert not t0._connected and not t1._connected
+
+
+def test_fused_exchange_kernels_build_and_keep_the_register_budget(tmp_path):
+    """The handle's second module (csrc/pi_push_kernels.hip appended to the sweep translation unit: the swept-first
+    kernel that delivers its rows itself, and the pair-level reach probe) builds for gfx950 in the sharded memory
+    orders through the library (pi_set_option 5 on a host-only handle) and through hipcc, where pi_eval_push_kernel
+    must stay inside the budget of the kernel it replaces in a sharded sweep: 64 VGPRs and 80 SGPRs on the 80^4 grid
+    (two 1 024-thread workgroups per CU), no scratch anywhere."""
+    import subprocess
+    import __graft_entry__ as G
+    push = (ROOT / "dynamicprogramming_amd" / "csrc" / "pi_push_kernels.hip").read_text()
+    for name, bins, vgprs in (("double_pendulum_swingup", 80, 64), ("double_cartpole", 25, 128)):
+        cls = envs.ENVS[name]
+        tables = [np.asarray(b, dtype=np.float32) for b in cls.bins_space(bins).values()]
+        eng = _native.Engine(cls._D, [len(t) for t in tables], [t.min() for t in tables], [t.max() for t in tables],
+                             tables, cls.ACTIONS, device=-1, order=cls.SHARDED_MEMORY_ORDER)
+        dyn = envs.dynamics_source(name)
+        eng.compile(dyn, cache_dir=tmp_path)
+        before = len(list(tmp_path.glob("pi_*.hsaco")))
+        eng.set_option(5, 1)                                  # second module -> cache
+        assert len(list(tmp_path.glob("pi_*.hsaco"))) == before + 1
+        src = tmp_path / f"{name}_push.hip"
+        src.write_text(eng.kernel_source(dyn) + push)
+        eng.close()
+        res = subprocess.run([G.HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "--genco",
+                              "-include", "hip/hip_runtime.h", "-Rpass-analysis=kernel-resource-usage", str(src),
+                              "-o", str(tmp_path / f"{name}_push.hsaco")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        usage, fn = {}, None
+        for line in res.stderr.splitlines():
+            if "Function Name:" in line:
+                fn = line.split("Function Name:")[1].split()[0]
+                usage[fn] = {}
+            elif fn and " VGPRs:" in line:
+                usage[fn]["vgpr"] = int(line.split("VGPRs:")[1].split()[0])
+            elif fn and "TotalSGPRs:" in line:
+                usage[fn]["sgpr"] = int(line.split("TotalSGPRs:")[1].split()[0])
+            elif fn and "ScratchSize" in line:
+                usage[fn]["scratch"] = int(line.split(":")[-1].split()[0])
+        assert {"pi_eval_push_kernel", "pi_reach_pairs_kernel"} <= set(usage)
+        k = usage["pi_eval_push_kernel"]
+        assert k["vgpr"] <= vgprs and k["scratch"] == 0 and usage["pi_reach_pairs_kernel"]["scratch"] == 0, (name, usage)
+        if name == "double_pendulum_swingup":
+            assert k["sgpr"] <= 80, k
+    # before pi_compile there is nothing to append to
+    eng = _host_engine("pendulum", (24, 17))
+    with pytest.raises(_native.NativeError, match="pi_compile has not run"):
+        eng.set_option(5, 1)
+    eng.close()
