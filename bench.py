@@ -250,6 +250,9 @@ ATTEMPT_TIMEOUT = 240.0
 # of the two as `value` and both under `value_by_transport`.
 BONUS_P2P = {"PI_MI355_TRANSPORT": "p2p", "PI_MI355_COMM_TIMEOUT": "30", "PI_BENCH_BONUS": "1"}
 BONUS_TIMEOUT = 150.0
+# ... and when NO RCCL rung works (a broken RCCL installation is not a reason to report nothing), the peer-to-peer transport
+# is the last rung of the ladder in its own right, complete line included.
+LADDER.append(("halo+overlap over p2p", {**BONUS_P2P, "PI_BENCH_BONUS": "0"}))
 
 
 def _free_port() -> int:
@@ -358,7 +361,7 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
             attempts.append(record)
             if record["ok"]:
                 line = got
-                if bonus_p2p and extra.get("PI_BENCH_MINIMAL") != "1":
+                if bonus_p2p and extra.get("PI_BENCH_MINIMAL") != "1" and extra.get("PI_MI355_TRANSPORT") != "p2p":
                     rec2, got2 = run_rung(len(ladder), mode + " over p2p", {**extra, **BONUS_P2P},
                                           min(attempt_timeout, BONUS_TIMEOUT))
                     bonus = dict(rec2)

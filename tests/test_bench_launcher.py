@@ -71,8 +71,9 @@ if mode == "halo":
 if mode.startswith("allgather"):
     assert os.environ.get("PI_MI355_EXCHANGE") == "allgather"
 assert (os.environ.get("PI_BENCH_MINIMAL") == "1") == (mode == "allgather-minimal")
-bonus = mode.endswith(" over p2p")                    # the best-effort rerun over the peer-to-peer transport
-assert (os.environ.get("PI_MI355_TRANSPORT") == "p2p") == bonus and (os.environ.get("PI_BENCH_BONUS") == "1") == bonus
+over_p2p = mode.endswith(" over p2p")                 # the ladder's last rung (attempt 4) or the best-effort rerun (5)
+bonus = over_p2p and attempt >= 5
+assert (os.environ.get("PI_MI355_TRANSPORT") == "p2p") == over_p2p and (os.environ.get("PI_BENCH_BONUS") == "1") == bonus
 if what == "hang":
     time.sleep(600)
 if what.startswith("exit"):
@@ -145,7 +146,7 @@ def test_the_faster_transport_is_reported_and_the_other_kept_beside_it(monkeypat
 
 
 def test_a_failing_p2p_rerun_costs_nothing():
-    plan = [["ok", "ok"], ["ok", "ok"], ["ok", "ok"], ["ok", "ok"], ["ok", "exit7"]]     # index 4 = the p2p rerun
+    plan = [["ok", "ok"]] * 5 + [["ok", "exit7"]]                        # index 5 = len(LADDER) = the p2p rerun
     (_, rc0, out0), (_, rc1, out1) = _run_supervisors(plan)
     assert (rc0, rc1) == (0, 0) and out1.strip() == ""
     obj = json.loads(out0.strip().splitlines()[-1])
@@ -177,8 +178,19 @@ def test_a_hung_rung_is_killed_at_the_time_limit_and_the_ladder_ends_in_allgathe
     # every rung had its own rendezvous port
 
 
+def test_the_peer_to_peer_rung_rescues_a_run_whose_rccl_rungs_all_fail():
+    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"], ["ok", "exit5"], ["ok", "ok"]], timeout=30.0)
+    (_, rc0, out0), (_, rc1, _) = got
+    assert (rc0, rc1) == (0, 0)
+    obj = json.loads(out0.strip().splitlines()[-1])
+    att = obj["check"]["exchange"]["attempts"]
+    assert [a["mode"] for a in att] == ["halo+overlap", "halo", "allgather", "allgather-minimal", "halo+overlap over p2p"]
+    assert [a["ok"] for a in att] == [False, False, False, False, True]
+    assert "p2p" not in obj["check"]["exchange"] and "value_by_transport" not in obj      # no rerun of a p2p rung over p2p
+
+
 def test_when_every_rung_fails_every_rank_fails():
-    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"], ["ok", "exit5"]], timeout=30.0)
+    got = _run_supervisors([["exit2", "ok"], ["ok", "exit2"], ["exit2", "exit2"], ["ok", "exit5"], ["exit9", "ok"]], timeout=30.0)
     assert [rc for _, rc, _ in got] == [1, 1]
     assert all(out.strip() == "" for _, _, out in got)                  # no result line is invented
 
@@ -189,7 +201,10 @@ def test_dry_run_shows_the_ladder():
                                                       if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert res.returncode == 0, res.stderr
     obj = json.loads(res.stdout.strip().splitlines()[-1])
-    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap", "halo", "allgather", "allgather-minimal"]
+    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap", "halo", "allgather", "allgather-minimal",
+                                                 "halo+overlap over p2p"]
+    assert obj["ladder"][4]["env"]["PI_MI355_TRANSPORT"] == "p2p" and obj["ladder"][4]["env"]["PI_BENCH_BONUS"] == "0"
+    assert obj["bonus_after_first_success"]["env"]["PI_BENCH_BONUS"] == "1"
     assert obj["ladder"][3]["env"]["PI_BENCH_MINIMAL"] == "1"
     assert obj["ladder"][2]["env"]["PI_MI355_EXCHANGE"] == "allgather" and obj["ladder"][0]["timeout_s"] == 240.0
     assert obj["worker"][1].endswith("bench.py")
