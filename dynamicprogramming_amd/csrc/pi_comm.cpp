@@ -508,6 +508,8 @@ int pi_comm_info(pi_handle* h, int what) {
         case 6: return h->plan && ((h->plan->row_exact && h->plan->push_ok) || h->plan->live_push_ok) ? 1 : 0;
         case 7: return h->plan && h->plan->pair_exact ? 1 : 0;
         case 8: return h->plan ? (int)std::min<int64_t>(h->plan->fused_send_elems, INT32_MAX) : -1;
+        case 9: return h->plan && (h->plan->row_exact || h->plan->live_exact) ? (int)std::min<int64_t>(h->plan->n_first, INT32_MAX) : -1;
+        case 10: return h->plan && (h->plan->row_exact || h->plan->live_exact) ? (int)std::min<int64_t>(h->plan->n_inner, INT32_MAX) : -1;
         default: return -1;
     }
 }

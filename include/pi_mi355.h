@@ -255,7 +255,8 @@ int pi_comm_destroy(pi_handle* h);
 /* 0 rank, 1 world, 2 transport (1 RCCL, 2 in-process, 3 peer-to-peer), 3 plan (0 none, 1 all-gather, 2 halo),
  * 4 granularity of the plan's reach probe (1 planes of dimension 0, 2 rows (i0, i1)), 5 row-exact plan (0 | 1),
  * 6 fused exchange (0 | 1), 7 destination masks cut down to the pairs (i_0, i_v) each peer reads (0 | 1; any memory order
- * with dimension 0 slowest), 8 values one fused sweep delivers, counted per receiver (-1: not a fused plan). */
+ * with dimension 0 slowest), 8 values one fused sweep delivers, counted per receiver (-1: not a fused plan), 9 / 10 entries of
+ * the swept-first / interior state lists of a row-exact or state-exact plan (-1: the plan sweeps ranges). */
 int pi_comm_info(pi_handle* h, int what);
 
 /* In-place collectives on the caller's stream: shard r of the buffer lives at r * shard_elems. */
