@@ -296,6 +296,11 @@ def result_line(text: str):
     return line
 
 
+def rehearsal_ladder():
+    """PI_BENCH_SHARE_GPU=1: the three exchange modes, each over the peer-to-peer transport (RCCL refuses two ranks on one GPU)."""
+    return [(m + " over p2p", {**e, **BONUS_P2P, "PI_BENCH_BONUS": "0"}) for m, e in LADDER[:3]]
+
+
 def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=None, bonus_p2p: bool = True) -> int:
     """One rank of an N-rank run as started by the launcher: never touches the GPU.  Runs the real rank as a child
     process, rung by rung of the fallback ladder, in lockstep with the other ranks' supervisors (gloo)."""
@@ -304,7 +309,7 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
     import torch
     import torch.distributed as dist
     if ladder is None and share_gpu():            # rehearsal on one GPU: only the peer-to-peer transport can run there
-        ladder = [(m + " over p2p", {**e, **BONUS_P2P, "PI_BENCH_BONUS": "0"}) for m, e in LADDER[:3]]
+        ladder = rehearsal_ladder()
         bonus_p2p = False
     ladder = LADDER if ladder is None else ladder
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -429,7 +434,10 @@ def self_launch(n_gpus: int, argv: list[str], dry_run: bool, attempt_timeout: fl
     cmd = launch_command(n_gpus, argv)
     if dry_run:
         print(json.dumps({"launch": cmd, "worker": worker_command(argv),
-                          "ladder": [{"mode": m, "env": e, "timeout_s": attempt_timeout} for m, e in LADDER],
+                          "ladder": [{"mode": m, "env": e, "timeout_s": attempt_timeout}
+                                     for m, e in (rehearsal_ladder() if share_gpu() else LADDER)],
+                          **({"rehearsal": "PI_BENCH_SHARE_GPU=1: the rank processes share ONE GPU; no best-effort rerun"}
+                             if share_gpu() else {}),
                           "bonus_after_first_success": {"mode": "<that rung> over p2p", "env": BONUS_P2P,
                                                         "timeout_s": min(attempt_timeout, BONUS_TIMEOUT),
                                                         "reported_as": "check.exchange.p2p", "affects_exit_code": False},

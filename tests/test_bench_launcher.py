@@ -210,6 +210,17 @@ def test_dry_run_shows_the_ladder():
     assert obj["worker"][1].endswith("bench.py")
 
 
+def test_dry_run_of_the_one_gpu_rehearsal_shows_its_own_ladder():
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PI_BENCH_SHARE_GPU"] = "1"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch-dry-run"], capture_output=True,
+                         text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    obj = json.loads(res.stdout.strip().splitlines()[-1])
+    assert [r["mode"] for r in obj["ladder"]] == ["halo+overlap over p2p", "halo over p2p", "allgather over p2p"]
+    assert all(r["env"]["PI_MI355_TRANSPORT"] == "p2p" for r in obj["ladder"]) and "rehearsal" in obj
+
+
 def test_self_launch_kills_a_child_that_overruns(monkeypatch):
     bench = _bench()
     monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, "-c", "import time; time.sleep(600)"])
