@@ -112,6 +112,13 @@ class OracleLib:
                                                _f32p, _f32p, _i32p, _i32p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_float, _i64p]
             lib.oracle_value_sweep.restype = ctypes.c_float
+        if hasattr(lib, "oracle_eval_points"):
+            lib.oracle_eval_points.argtypes = [ctypes.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _i32p,
+                                               ctypes.c_float, _f32p]
+            lib.oracle_eval_points.restype = None
+            lib.oracle_improve_points.argtypes = [ctypes.c_int64, _f32p, _f32p, ctypes.c_int32, _f32p, _f32p, _f32p,
+                                                  _i32p, _i32p, ctypes.c_float, _i32p, _f32p]
+            lib.oracle_improve_points.restype = None
         lib.oracle_run.argtypes = [_f32p, _f32p, ctypes.c_int32, _i32p, _f32p, _f32p, _u8p, _f32p,
                                    _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_int32, ctypes.c_int32, _f32p, _i64p, _i32p]
@@ -200,6 +207,32 @@ class OracleLib:
                                              _p(shape, _i32p), _p(strides, _i32p), s0, s1,
                                              np.float32(gamma), _p(changed, _i64p))
         return newV, policy, float(delta), int(changed[0])
+
+    # -- the same backups for a list of states (coordinates) ------------------------
+    def eval_points(self, coords, action_values, V, lo, hi, shape, strides, gamma):
+        """V'(s) = r + gamma E[V](s') for the non-terminal states at `coords` (m, D) under the action VALUES
+        `action_values` (m,); V is the whole table in the reference's flat order."""
+        coords = _f32(coords).reshape(-1, self.D)
+        m = len(coords)
+        act, V = _f32(np.broadcast_to(action_values, (m,))), _f32(V)
+        lo, hi, shape, strides = _f32(lo), _f32(hi), _i32(shape), _i32(strides)
+        out = np.empty(m, dtype=np.float32)
+        self._lib.oracle_eval_points(m, _p(coords, _f32p), _p(act, _f32p), _p(V, _f32p), _p(lo, _f32p), _p(hi, _f32p),
+                                     _p(shape, _i32p), _p(strides, _i32p), np.float32(gamma), _p(out, _f32p))
+        return out
+
+    def improve_points(self, coords, actions, V, lo, hi, shape, strides, gamma):
+        """(greedy action index, its value) of the states at `coords` (m, D): strict '>' from -1e30."""
+        coords = _f32(coords).reshape(-1, self.D)
+        m = len(coords)
+        actions, V = _f32(actions), _f32(V)
+        lo, hi, shape, strides = _f32(lo), _f32(hi), _i32(shape), _i32(strides)
+        best = np.empty(m, dtype=np.int32)
+        best_q = np.empty(m, dtype=np.float32)
+        self._lib.oracle_improve_points(m, _p(coords, _f32p), _p(actions, _f32p), len(actions), _p(V, _f32p),
+                                        _p(lo, _f32p), _p(hi, _f32p), _p(shape, _i32p), _p(strides, _i32p),
+                                        np.float32(gamma), _p(best, _i32p), _p(best_q, _f32p))
+        return best, best_q
 
     # -- run() ------------------------------------------------------------------
     def run(self, states, actions, is_term, lo, hi, shape, strides, gamma, theta, max_eval_iter,

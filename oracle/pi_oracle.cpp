@@ -15,6 +15,7 @@
  *   oracle_run           policy_evaluation :300-336, policy_improvement :338-355,
  *                        run :357-370  (delta looked at on sweeps 0,25,50,.. and the last)
  *   oracle_step          thin batch driver over the plugged `step_dynamics`.
+ *   oracle_eval_points / oracle_improve_points   the same backups for a list of states (coordinates).
  *
  * Built once per (D, dynamics string) by oracle/__init__.py:
  *   g++ -O2 -mfma -msse4.1 -ffp-contract=off -fopenmp -shared -fPIC
@@ -236,6 +237,36 @@ float oracle_value_sweep(const float* states, const float* actions, int32_t n_ac
     }
     if (changed_out) *changed_out = changed;
     return delta;
+}
+
+/* The same backups for a LIST of states given by their coordinates instead of a range of the
+ * reference's flat order: tests of grids that the product holds in another memory order check windows of
+ * MEMORY-order indices, which are scattered in the reference's order.  V is the whole table in the
+ * reference's order.  eval: out[k] = backup(coords[k], action_values[k]) (:616-649 for one non-terminal
+ * state; the caller handles terminal states).  improve: best[k] / best_q[k] of the strict-'>' argmax
+ * from -1e30 (:651-691). */
+void oracle_eval_points(int64_t m, const float* coords, const float* action_values, const float* V,
+                        const float* lo, const float* hi, const int32_t* g, const int32_t* st,
+                        float gamma, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < m; ++k)
+        out[k] = backup(coords + k * PI_D, action_values[k], V, lo, hi, g, st, gamma);
+}
+
+void oracle_improve_points(int64_t m, const float* coords, const float* actions, int32_t n_actions,
+                           const float* V, const float* lo, const float* hi, const int32_t* g,
+                           const int32_t* st, float gamma, int32_t* best, float* best_q) {
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < m; ++k) {
+        float max_q = -1.0e30f;
+        int b = 0;
+        for (int a = 0; a < n_actions; ++a) {
+            float q = backup(coords + k * PI_D, actions[a], V, lo, hi, g, st, gamma);
+            if (q > max_q) { max_q = q; b = a; }
+        }
+        best[k] = b;
+        if (best_q) best_q[k] = max_q;
+    }
 }
 
 /*

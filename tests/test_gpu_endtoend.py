@@ -402,59 +402,6 @@ def test_device_inference_matches_the_reference_function(cuda_device):
                      device=cuda_device)
 
 
-def test_full_size_c5_swingup_windows(cuda_device):
-    """BASELINE config C5, swing-up variant (double_cartpole_swingup 25^6 = 244 140 625 states x 9
-    forces; reference runners/double_cartpole_swingup_cuda.py:114-238, kernels
-    src/cuda_policy_iteration.py:1007-1131) at FULL size: one evaluation sweep checked by the residual
-    (== torch reduction), terminal copies and oracle windows at the start, middle and end; windowed
-    improvement sweeps over all 9 actions against the oracle (policy and changed-count exact).  The angle
-    dimensions wrap, successors reach far (7-9 cells of theta-dot), and six trig calls and two angle
-    wraps per action run per state — the heaviest kernel of the package."""
-    torch = _torch()
-    name, shape = "double_cartpole_swingup", (25,) * 6
-    cls = envs.ENVS[name]
-    n = 25 ** 6
-    bins = H.env_bins(name, shape)
-    acts = np.asarray(cls.ACTIONS, np.float32)
-    assert len(acts) == 9
-    eng = _native.Engine(6, [25] * 6, [b.min() for b in bins], [b.max() for b in bins], bins, acts,
-                         device=cuda_device.index or 0)
-    eng.compile(envs.dynamics_source(name))
-    gamma = float(np.float32(cls.CONFIG["gamma"]))
-    gen = torch.Generator(device="cpu").manual_seed(11)
-    V = torch.randn(n, generator=gen, dtype=torch.float32) * 20.0
-    pol = torch.randint(0, 9, (n,), generator=gen, dtype=torch.int32)
-    term = torch.zeros(shape, dtype=torch.bool)
-    term |= torch.from_numpy(np.abs(bins[0]) > 2.4).view(25, 1, 1, 1, 1, 1)          # _terminal_fn: |x| > 2.4
-    term = term.reshape(-1).to(torch.uint8)
-    d_V, d_pol, d_term = V.to(cuda_device), pol.to(cuda_device), term.to(cuda_device)
-    d_Vn = torch.empty_like(d_V)
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, d_delta.data_ptr())
-    torch.cuda.synchronize()
-    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
-    tmask = d_term.bool()
-    assert int(tmask.sum()) == 2 * 25 ** 5 and torch.equal(d_Vn[tmask], d_V[tmask])
-    chk = H.oracle_for(name)
-    lo, hi, gshape, strides = oracle.grid_metadata(bins)
-    Vh, polh, termh = V.numpy(), pol.numpy(), term.numpy()
-    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
-    plane0 = 25 ** 5                                                 # first non-terminal x plane starts here
-    for a, b in [(plane0, plane0 + 1536), (n // 2 - 1000, n // 2 + 1000), (n - plane0 - 1536, n - plane0), (n - 600, n)]:
-        sub = np.arange(a, b)
-        idx = np.stack(np.unravel_index(sub, shape), axis=1)
-        pad_states = np.zeros((b, 6), dtype=np.float32)              # calloc: only rows [a, b) are ever touched
-        pad_states[a:b] = np.stack([bins[d][idx[:, d]] for d in range(6)], axis=1)
-        o_Vn = np.zeros(b, dtype=np.float32)
-        chk.eval_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape, strides, gamma, a, b, out=o_Vn)
-        H.assert_bits_equal(d_Vn[a:b].cpu().numpy(), o_Vn[a:b], f"C5 swing-up eval window [{a},{b})")
-        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, d_changed.data_ptr())
-        o_pol, o_changed = chk.improve_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape, strides,
-                                             gamma, a, b)
-        assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
-        assert int(d_changed.item()) == o_changed
-        del pad_states, o_Vn
-    eng.close()
 
 
 def test_plan_ranges_tile_the_shard_and_a_missing_peer_is_an_error_not_a_hang(cuda_device, monkeypatch):

@@ -1,0 +1,263 @@
+"""
+Full-size GPU parity of the BASELINE configs — in the memory orders the product really runs them in.
+
+Every real single-rank run of C4 / C5 / C5-swing-up (and bench.py) holds its device arrays with the grid's dimensions
+permuted (solver.MEMORY_ORDER, envs.py), and solvers sharded over the peer-to-peer transport use
+SHARDED_MEMORY_ORDER.  These tests run the size-independent properties and the oracle windows of SURVEY section 8(c)
+at the FULL grid sizes for every such order: C3 50^4, C4 80^4, C5 25^6 and the 9-action swing-up variant of C5, each in
+the env's own order, the single-rank order and the sharded order.  Windows are ranges of MEMORY-order indices (what a
+launch range, a shard and a chunk are made of); the oracle, which works in the reference's order, is asked for exactly
+those states through its point-list entry (oracle_eval_points / oracle_improve_points).  Bar: bit for bit.
+
+Reference kernels served: /root/reference/src/cuda_policy_iteration.py:616-649 and :651-691 (4-D), :1044-1079 and
+:1081-1123 (6-D).
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+from dynamicprogramming_amd import _native, envs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _bins_mask(shape, bad_per_dim):
+    """bool tensor of the grid's shape: True where any dimension's index is flagged (terminal regions that are unions of
+    slabs — every BASELINE env's are — without materialising the (n, D) states array)."""
+    torch = _torch()
+    term = torch.zeros(tuple(shape), dtype=torch.bool)
+    for d, bad in enumerate(bad_per_dim):
+        if bad is None or not np.any(bad):
+            continue
+        view = [1] * len(shape)
+        view[d] = shape[d]
+        term |= torch.from_numpy(np.asarray(bad, dtype=bool)).view(view)
+    return term.reshape(-1)
+
+
+def _term_c3(bins, shape):
+    states = oracle.states_from_bins(bins)
+    mask, _ = H.terminal_mask("cartpole_swingup", states)
+    return _torch().from_numpy(np.ascontiguousarray(mask))
+
+
+def _term_c5(bins, shape):
+    lim = envs.DoubleCartPoleCuda._TH_FAIL               # |x| > 2.4 or |theta| > 20 degrees (envs.py: _terminal_fn)
+    return _bins_mask(shape, [np.abs(bins[0]) > 2.4, None, np.abs(bins[2]) > lim, None, np.abs(bins[4]) > lim, None])
+
+
+def _term_c5_swingup(bins, shape):
+    return _bins_mask(shape, [np.abs(bins[0]) > 2.4] + [None] * 5)
+
+
+# config -> (env, bins per dimension, seed, V scale, terminal mask builder, ways of the ragged shard-invariance split,
+#            window half-widths (states) at the start / middle / end of the MEMORY-order index range)
+CONFIGS = {
+    "c3": ("cartpole_swingup", 50, 2, 1.0, _term_c3, 3, 30_000),
+    "c4": ("double_pendulum_swingup", 80, 0, 1.0, None, 4, 3_000),
+    "c5": ("double_cartpole", 25, 1, 1.0, _term_c5, 8, 1_500),
+    "c5_swingup": ("double_cartpole_swingup", 25, 11, 20.0, _term_c5_swingup, 8, 1_000),
+}
+
+
+def _orders(cfg):
+    """(id, order) pairs: the env's own order, the class's single-rank order and its sharded order (distinct ones).  C3
+    has no tuned order (the measured differences were inside the noise): it is run once in a permuted order anyway."""
+    cls = envs.ENVS[CONFIGS[cfg][0]]
+    out = [("env-order", None)]
+    if cls.MEMORY_ORDER is not None:
+        out.append(("single-rank-order", tuple(cls.MEMORY_ORDER)))
+    if cls.SHARDED_MEMORY_ORDER is not None and cls.SHARDED_MEMORY_ORDER != cls.MEMORY_ORDER:
+        out.append(("sharded-order", tuple(cls.SHARDED_MEMORY_ORDER)))
+    if cls.MEMORY_ORDER is None:
+        out.append(("permuted-order", (0, 2, 1, 3)))
+    return out
+
+
+CASES = [pytest.param(cfg, order, id=f"{cfg}-{oid}") for cfg in CONFIGS for oid, order in _orders(cfg)]
+
+
+def _user_index_of_memory_range(a, b, shape, order):
+    """Memory-order flat indices [a, b) -> (per-dimension USER indices (m, D), USER flat indices (m,))."""
+    D = len(shape)
+    order = tuple(range(D)) if order is None else order
+    mem_shape = [shape[d] for d in order]
+    idx_mem = np.stack(np.unravel_index(np.arange(a, b, dtype=np.int64), mem_shape), axis=1)
+    idx_user = np.empty_like(idx_mem)
+    for k, d in enumerate(order):
+        idx_user[:, d] = idx_mem[:, k]
+    return idx_user, np.ravel_multi_index(tuple(idx_user.T), shape)
+
+
+@pytest.mark.parametrize("cfg,order", CASES)
+def test_full_size_properties_and_oracle_windows_in_every_production_order(cfg, order, cuda_device):
+    torch = _torch()
+    name, nb, seed, scale, term_fn, ways, half = CONFIGS[cfg]
+    cls = envs.ENVS[name]
+    D = cls._D
+    shape = (nb,) * D
+    n = nb ** D
+    bins = H.env_bins(name, shape)
+    acts = np.asarray(cls.ACTIONS, np.float32)
+    eng = _native.Engine(D, list(shape), [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0, order=order)
+    eng.compile(envs.dynamics_source(name))
+    assert eng.order == (tuple(range(D)) if order is None else tuple(order))
+    gamma = float(np.float32(cls.CONFIG["gamma"]))
+    # seeded inputs in the USER's order (what the oracle sees); the device gets them in the engine's memory order
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    V = torch.randn(n, generator=gen, dtype=torch.float32) * scale
+    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
+    term = None if term_fn is None else term_fn(bins, shape).to(torch.uint8)
+    d_V = eng.to_memory(V.to(cuda_device))
+    d_pol = eng.to_memory(pol.to(cuda_device))
+    d_term = None if term is None else eng.to_memory(term.to(cuda_device))
+    tptr = 0 if d_term is None else d_term.data_ptr()
+    d_Vn = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), tptr, 0, n, gamma, d_delta.data_ptr())
+    torch.cuda.synchronize()
+    # residual == max |V' - V| computed independently; every state written
+    assert not bool(torch.isnan(d_Vn).any())
+    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
+    if d_term is not None:
+        tmask = d_term.bool()
+        assert int(tmask.sum()) > 0 and torch.equal(d_Vn[tmask], d_V[tmask])          # terminal states copy their value
+        del tmask
+    # the ragged `ways`-way split of the MEMORY-order range the multi-GPU path uses == the whole sweep, bit for bit
+    per = -(-n // ways)
+    d_Vs = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    for r in range(ways):
+        a, b = min(r * per, n), min((r + 1) * per, n)
+        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), tptr, a, b, gamma, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_Vs.view(torch.int32), d_Vn.view(torch.int32))
+    del d_Vs
+    if D == 4:
+        # the backup is affine in V for a fixed policy: T(V + c) - T(V) = gamma c wherever the successor bootstraps
+        d_V8 = d_V + 8.0
+        d_Vc = torch.empty_like(d_V)
+        eng.eval_sweep(d_V8.data_ptr(), d_Vc.data_ptr(), d_pol.data_ptr(), tptr, 0, n, gamma, 0)
+        torch.cuda.synchronize()
+        diff = d_Vc - d_Vn
+        if d_term is None:
+            assert float((diff - gamma * 8.0).abs().max().item()) < 5e-5
+        else:
+            live = diff[~d_term.bool()]                                               # done successors: difference 0
+            assert float(torch.minimum((live - gamma * 8.0).abs(), live.abs()).max().item()) < 5e-5
+        del d_V8, d_Vc, diff
+        # contraction: |T V1 - T V2|_inf <= gamma |V1 - V2|_inf (+ rounding)
+        d_V2 = d_V * 0.5
+        d_Vn2 = torch.empty_like(d_V)
+        eng.eval_sweep(d_V2.data_ptr(), d_Vn2.data_ptr(), d_pol.data_ptr(), tptr, 0, n, gamma, 0)
+        torch.cuda.synchronize()
+        assert float((d_Vn - d_Vn2).abs().max()) <= max(gamma, 1.0 if d_term is not None else gamma) * float((d_V - d_V2).abs().max()) + 1e-4
+        del d_V2, d_Vn2
+    # oracle windows: ranges of memory-order indices at the start, in the middle (row / plane crossings) and at the end
+    chk = H.oracle_for(name)
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    Vh, polh = V.numpy(), pol.numpy()
+    termh = None if term is None else term.numpy()
+    windows = [(0, 2 * half), (n // 2 - half, n // 2 + half), (n - 2 * half - 1, n)]
+    if cfg == "c5_swingup":                                    # first / last non-terminal x plane when x is slowest
+        windows += [(nb ** 5, nb ** 5 + half), (n - nb ** 5 - half, n - nb ** 5)]
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    for a, b in windows:
+        idx_user, flat_user = _user_index_of_memory_range(a, b, shape, order)
+        coords = np.stack([bins[d][idx_user[:, d]] for d in range(D)], axis=1).astype(np.float32)
+        t = np.zeros(b - a, dtype=bool) if termh is None else termh[flat_user].astype(bool)
+        want = chk.eval_points(coords, acts[polh[flat_user]], Vh, lo, hi, gshape, strides, gamma)
+        want[t] = Vh[flat_user][t]
+        H.assert_bits_equal(d_Vn[a:b].cpu().numpy(), want, f"{cfg} {order} eval window [{a},{b})")
+        d_p2 = d_pol.clone()
+        eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), tptr, a, b, gamma, d_changed.data_ptr())
+        best, _ = chk.improve_points(coords, acts, Vh, lo, hi, gshape, strides, gamma)
+        old = polh[flat_user]
+        best[t] = old[t]                                       # terminal states keep their entry (:253)
+        assert np.array_equal(d_p2[a:b].cpu().numpy(), best), f"{cfg} {order} improve window [{a},{b})"
+        assert int(d_changed.item()) == int(np.count_nonzero(best != old))
+        assert torch.equal(d_p2[:a], d_pol[:a]) and torch.equal(d_p2[b:], d_pol[b:])   # nothing outside the range
+        del d_p2
+    eng.close()
+
+
+def _whole_grid_reference(solver, V_user, pol_user, n_eval, cuda_device, begin_end=False):
+    """`n_eval` evaluation sweeps + one improvement sweep over the whole grid on an identity-order engine WITHOUT any
+    list (plain pi_eval_sweep / pi_improve_sweep, one call per sweep — the kernels the oracle windows above pin),
+    from the user-order state (V_user, pol_user) on the device.  Returns (V, policy, residual, changed) in user order."""
+    torch = _torch()
+    cls = type(solver)
+    D, n = cls._D, solver.n_states
+    eng = _native.Engine(D, solver.grid_shape, solver.bounds_low, solver.bounds_high, solver._bins, solver.action_space,
+                         device=cuda_device.index or 0)
+    eng.compile(solver._dynamics_cuda_src())
+    assert eng.info(16) == 0                                     # no live-state list on this engine
+    term_user = solver._to_user(solver.d_terminal_mask[:n]) if solver._mask_arg() is not None else None
+    tptr = 0 if term_user is None else term_user.data_ptr()
+    A, B, P = V_user.clone(), V_user.clone(), pol_user.clone()
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    gamma = float(np.float32(solver.config.gamma))
+    for i in range(n_eval):
+        eng.eval_sweep(A.data_ptr(), B.data_ptr(), P.data_ptr(), tptr, 0, n, gamma, d_delta.data_ptr() if i == n_eval - 1 else 0)
+        A, B = B, A
+    eng.improve_sweep(A.data_ptr(), P.data_ptr(), tptr, 0, n, gamma, d_changed.data_ptr())
+    torch.cuda.synchronize()
+    out = (A, P, float(d_delta.item()), int(d_changed.item()))
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("name,bins,n_eval", [("double_pendulum_swingup", 80, 2), ("double_cartpole", 25, 5),
+                                              ("double_cartpole_swingup", 25, 2)])
+def test_the_bench_path_in_its_memory_order_equals_the_identity_order_engine(name, bins, n_eval, cuda_device):
+    """The path bench.py times and every real run takes — envs.make(...) picks the class's MEMORY_ORDER, the solver
+    prepares the live-state list and brackets its evaluation (per-evaluation list), `_evaluation_sweeps(k)` +
+    `_improvement_sweep()` go through batches, lists and the permuted strides — against the plain one-sweep-per-call
+    kernels of an identity-order engine (which the oracle windows above pin at this size): V, policy, residual and the
+    change count over the WHOLE grid, bit for bit."""
+    torch = _torch()
+    solver = envs.make(name, bins, device=cuda_device)
+    cls = type(solver)
+    n = solver.n_states
+    assert solver._order == tuple(cls.MEMORY_ORDER) and solver._backend.engine.order == tuple(cls.MEMORY_ORDER)
+    gamma = float(np.float32(solver.config.gamma))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    V_user = torch.randn(n, generator=gen, dtype=torch.float32).to(cuda_device)
+    pol_user = torch.randint(0, solver.n_actions, (n,), generator=gen, dtype=torch.int32).to(cuda_device)
+    if solver._mask_arg() is not None:                          # terminal states keep the solver's seeding (value 0, entry 0)
+        t_user = solver._to_user(solver.d_terminal_mask[:n]).bool()
+        V_user[t_user] = 0.0
+        pol_user[t_user] = 0
+        del t_user
+    solver.d_value_function[:n].copy_(solver._to_memory(V_user))
+    solver.d_new_value_function.copy_(solver.d_value_function)
+    solver.d_policy[:n].copy_(solver._to_memory(pol_user))
+    eng = solver._backend.engine
+    if name == "double_cartpole":
+        assert eng.info(16) > 0                                  # the live-state list is in use on this grid
+    solver._backend.eval_begin(solver.d_policy, solver._mask_arg())         # as policy_evaluation() brackets its loop
+    try:
+        if name == "double_cartpole":
+            assert eng.info(17) > 0                              # ... and so is the per-evaluation list
+        solver._evaluation_sweeps(n_eval, gamma)
+    finally:
+        solver._backend.eval_end()
+    solver._improvement_sweep(gamma)
+    torch.cuda.synchronize()
+    got_V = solver._to_user(solver.d_value_function[:n])
+    got_P = solver._to_user(solver.d_policy[:n])
+    residual, changed = float(solver._d_delta.item()), int(solver._d_changed.item())
+    want_V, want_P, want_residual, want_changed = _whole_grid_reference(solver, V_user, pol_user, n_eval, cuda_device)
+    assert torch.equal(got_V.view(torch.int32), want_V.view(torch.int32)), f"{name}: V differs from the identity-order engine"
+    assert torch.equal(got_P, want_P), f"{name}: policy differs from the identity-order engine"
+    assert residual == want_residual and changed == want_changed
+    solver._backend.close()

@@ -261,74 +261,6 @@ def test_c2_full_run_matches_oracle(cuda_device):
     H.assert_bits_equal(solver.value_function, ref["value_function"], "C2 V")
 
 
-def test_full_size_c4_properties(cuda_device):
-    """BASELINE config C4 (double pendulum 80^4 x 11 actions = 40.96 M states) at full size:
-    size-independent properties + oracle spot-check of whole 256-state chunks."""
-    torch = _torch()
-    name, shape = "double_pendulum_swingup", (80, 80, 80, 80)
-    eng, bins, acts = _engine(name, shape, cuda_device)
-    n = int(np.prod(shape))
-    gamma = float(np.float32(0.999))
-    gen = torch.Generator(device="cpu").manual_seed(0)
-    V = torch.randn(n, generator=gen, dtype=torch.float32)
-    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
-    d_V, d_pol = V.to(cuda_device), pol.to(cuda_device)
-    d_term = torch.zeros(n, dtype=torch.uint8, device=cuda_device)
-    d_Vn = torch.empty_like(d_V)
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
-                   d_delta.data_ptr())
-    torch.cuda.synchronize()
-    # residual == max|V' - V| computed independently
-    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
-    # sharded == unsharded, bit for bit (what the multi-GPU path relies on)
-    d_Vs = torch.empty_like(d_V)
-    for r in range(4):
-        a, b = r * (n // 4), (r + 1) * (n // 4)
-        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b,
-                       gamma, 0)
-    torch.cuda.synchronize()
-    assert torch.equal(d_Vs, d_Vn)
-    # linearity of the evaluation operator in V for a fixed policy: T(V + c) - T(V) = gamma*c
-    # (up to fp32 rounding of the interpolation weights, which sum to 1 within a few ulp)
-    d_Vc = torch.empty_like(d_V)
-    d_V8 = d_V + 8.0
-    eng.eval_sweep(d_V8.data_ptr(), d_Vc.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n,
-                   gamma, 0)
-    torch.cuda.synchronize()
-    assert float((d_Vc - d_Vn - gamma * 8.0).abs().max().item()) < 5e-5
-    # contraction: |T V1 - T V2|_inf <= gamma |V1 - V2|_inf (+ rounding)
-    d_V2 = d_V * 0.5
-    d_Vn2 = torch.empty_like(d_V)
-    eng.eval_sweep(d_V2.data_ptr(), d_Vn2.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
-    torch.cuda.synchronize()
-    assert float((d_Vn - d_Vn2).abs().max()) <= gamma * float((d_V - d_V2).abs().max()) + 1e-4
-    # oracle spot check: whole chunks at the start, the middle (row/plane crossings) and the end
-    chk = H.oracle_for(name)
-    lo, hi, gshape, strides = oracle.grid_metadata(bins)
-    Vh, polh = V.numpy(), pol.numpy()
-    Vn_h = d_Vn.cpu().numpy()
-    # improve on a window, then compare both against the oracle restricted to the window
-    windows = [(0, 4096), (n // 2 - 3000, n // 2 + 3000), (n - 5000, n)]
-    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
-    for a, b in windows:
-        sub = np.arange(a, b)
-        idx = np.stack(np.unravel_index(sub, shape), axis=1)
-        st = np.stack([bins[d][idx[:, d]] for d in range(4)], axis=1).astype(np.float32)
-        # oracle on the window: states array holds only the window rows, shifted indexing
-        pad_states = np.zeros((b, 4), dtype=np.float32)
-        pad_states[a:b] = st
-        o_Vn = np.zeros(b, dtype=np.float32)
-        chk.eval_sweep(pad_states, acts, polh[:b], Vh, np.zeros(b, np.uint8), lo, hi, gshape,
-                       strides, gamma, a, b, out=o_Vn)
-        H.assert_bits_equal(Vn_h[a:b], o_Vn[a:b], f"C4 eval window [{a},{b})")
-        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
-                          d_changed.data_ptr())
-        o_pol, o_changed = chk.improve_sweep(pad_states, acts, polh[:b], Vh, np.zeros(b, np.uint8),
-                                             lo, hi, gshape, strides, gamma, a, b)
-        assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
-        assert int(d_changed.item()) == o_changed
-    eng.close()
 
 
 def test_error_paths(cuda_device):
@@ -412,65 +344,6 @@ def test_value_sweep_bit_exact(name, shape, cuda_device):
     eng.close()
 
 
-def test_full_size_c5_properties(cuda_device):
-    """BASELINE config C5 (double cartpole 25^6 = 244 140 625 states, n odd) at full size on one
-    GPU: residual, shard invariance with the ragged 8-way split the multi-GPU path uses, terminal
-    states copied, oracle windows (64-corner interpolation, int32 indices near 2^28)."""
-    torch = _torch()
-    name, shape = "double_cartpole", (25,) * 6
-    eng, bins, acts = _engine(name, shape, cuda_device)
-    n = 25 ** 6
-    gamma = float(np.float32(0.999))
-    gen = torch.Generator(device="cpu").manual_seed(1)
-    V = torch.randn(n, generator=gen, dtype=torch.float32)
-    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
-    # terminal mask from the bin tables (|x| > 2.4 or |theta| > 20 deg), without the (n, 6) array
-    lim = envs.DoubleCartPoleCuda._TH_FAIL
-    bad = [np.abs(bins[0]) > 2.4, np.zeros(25, bool), np.abs(bins[2]) > lim, np.zeros(25, bool),
-           np.abs(bins[4]) > lim, np.zeros(25, bool)]
-    term = torch.zeros(shape, dtype=torch.bool)
-    for d, b in enumerate(bad):
-        view = [1] * 6
-        view[d] = 25
-        term |= torch.from_numpy(b).view(view)
-    term = term.reshape(-1).to(torch.uint8)
-    d_V, d_pol, d_term = V.to(cuda_device), pol.to(cuda_device), term.to(cuda_device)
-    d_Vn = torch.empty_like(d_V)
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
-                   d_delta.data_ptr())
-    torch.cuda.synchronize()
-    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
-    tmask = d_term.bool()
-    assert torch.equal(d_Vn[tmask], d_V[tmask]) and int(tmask.sum()) > 0
-    per = -(-n // 8)
-    d_Vs = torch.empty_like(d_V)
-    for r in range(8):
-        a, b = min(r * per, n), min((r + 1) * per, n)
-        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, 0)
-    torch.cuda.synchronize()
-    assert torch.equal(d_Vs, d_Vn)
-    chk = H.oracle_for(name)
-    lo, hi, gshape, strides = oracle.grid_metadata(bins)
-    Vh, polh, termh = V.numpy(), pol.numpy(), term.numpy()
-    Vn_h = d_Vn.cpu().numpy()
-    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
-    for a, b in [(0, 2048), (n // 2 - 1500, n // 2 + 1500), (n - 2048, n)]:
-        sub = np.arange(a, b)
-        idx = np.stack(np.unravel_index(sub, shape), axis=1)
-        pad_states = np.zeros((b, 6), dtype=np.float32)          # only rows [a, b) are touched
-        pad_states[a:b] = np.stack([bins[d][idx[:, d]] for d in range(6)], axis=1)
-        o_Vn = np.zeros(b, dtype=np.float32)
-        chk.eval_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape, strides, gamma, a, b,
-                       out=o_Vn)
-        H.assert_bits_equal(Vn_h[a:b], o_Vn[a:b], f"C5 eval window [{a},{b})")
-        eng.improve_sweep(d_V.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma,
-                          d_changed.data_ptr())
-        o_pol, o_changed = chk.improve_sweep(pad_states, acts, polh[:b], Vh, termh[:b], lo, hi, gshape,
-                                             strides, gamma, a, b)
-        assert np.array_equal(d_pol[a:b].cpu().numpy(), o_pol[a:b])
-        assert int(d_changed.item()) == o_changed
-    eng.close()
 
 
 @pytest.mark.parametrize("name", ["cartpole", "double_pendulum_swingup", "double_cartpole"])
@@ -795,56 +668,6 @@ def test_sharded_driver_local_transport(world, name, shape, mode, cuda_device, m
             assert info["send_ranges"] >= 1 and 0 < info["recv_elems"] < (world - 1) * -(-single.n_states // world)
 
 
-def test_full_size_c3_properties(cuda_device):
-    """BASELINE config C3 (cartpole swing-up 50^4 = 6.25 M states x 5 actions) at full size:
-    residual, shard invariance, terminal states copied, linearity in V, oracle windows."""
-    torch = _torch()
-    name, shape = "cartpole_swingup", (50,) * 4
-    eng, bins, acts = _engine(name, shape, cuda_device)
-    n = 50 ** 4
-    gamma = float(np.float32(0.999))
-    gen = torch.Generator(device="cpu").manual_seed(2)
-    V = torch.randn(n, generator=gen, dtype=torch.float32)
-    pol = torch.randint(0, len(acts), (n,), generator=gen, dtype=torch.int32)
-    states = oracle.states_from_bins(bins)
-    term_np, _ = H.terminal_mask(name, states)
-    assert term_np.any()
-    d_V, d_pol = V.to(cuda_device), pol.to(cuda_device)
-    d_term = _dev(term_np.astype(np.uint8), cuda_device)
-    d_Vn = torch.empty_like(d_V)
-    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
-    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma,
-                   d_delta.data_ptr())
-    torch.cuda.synchronize()
-    assert float(d_delta.item()) == float((d_Vn - d_V).abs().max().item())
-    tmask = d_term.bool()
-    assert torch.equal(d_Vn[tmask], d_V[tmask])
-    per = -(-n // 3)
-    d_Vs = torch.empty_like(d_V)
-    for r in range(3):
-        a, b = min(r * per, n), min((r + 1) * per, n)
-        eng.eval_sweep(d_V.data_ptr(), d_Vs.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, 0)
-    torch.cuda.synchronize()
-    assert torch.equal(d_Vs, d_Vn)
-    # the backup is affine in V: T(V + c) - T(V) = gamma * c on non-terminal, non-terminating states
-    d_V2 = d_V + 8.0
-    d_Vn2 = torch.empty_like(d_V)
-    eng.eval_sweep(d_V2.data_ptr(), d_Vn2.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
-    diff = (d_Vn2 - d_Vn)[~tmask]
-    assert float((diff - 8.0 * gamma).abs().max().item()) < 2e-5 or float(diff.min().item()) >= 0.0
-    chk = H.oracle_for(name)
-    lo, hi, gshape, strides = oracle.grid_metadata(bins)
-    Vh, polh = V.numpy(), pol.numpy()
-    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
-    for a, b in ((0, 70_000), (n // 2 - 5, n // 2 + 50_000), (n - 60_001, n)):
-        o_Vn, _ = chk.eval_sweep(states, acts, polh, Vh, term_np, lo, hi, gshape, strides, gamma, a, b)
-        H.assert_bits_equal(d_Vn[a:b].cpu().numpy(), o_Vn[a:b], f"C3 window [{a},{b})")
-        d_p2 = d_pol.clone()
-        eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), a, b, gamma, d_changed.data_ptr())
-        o_pol, o_changed = chk.improve_sweep(states, acts, polh, Vh, term_np, lo, hi, gshape, strides, gamma, a, b)
-        assert np.array_equal(d_p2[a:b].cpu().numpy(), o_pol[a:b])
-        assert int(d_changed.item()) == o_changed
-    eng.close()
 
 
 def test_runner_script_end_to_end(cuda_device, tmp_path):
