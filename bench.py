@@ -35,29 +35,36 @@ sweeps of the same state (`check.exchange.bit_identical`); a mismatch fails the 
 
 Prints ONE JSON line on rank 0 (contract in the task statement), plus
   roofline      — dominant kernel of the step (pi_eval_sweep_kernel in every BASELINE config; pi_eval_live_kernel,
-                  the same sweep over the listed non-terminal states, on the double cartpole grid).  These sweeps
-                  are a divergent gather plus 300-600 fp32 VALU instructions of dynamics per state; the
-                  committed PMC profile of THIS kernel version and THIS config (profiles/rNN/
-                  counters_bench_<config>.json, matched on env, bins and the hash of the device code) gives
-                  the work per launch, the launch time is measured live (HIP events on the launch stream),
-                  and three units are priced, each against its hardware peak:
+                  the same sweep over the listed non-terminal states, on the double cartpole grid).  The headline
+                  fraction is the one the north star names: HBM-side bytes per launch — rocprofv3 FETCH_SIZE x 2.0 +
+                  WRITE_SIZE from the committed PMC profile of THIS kernel version and THIS config (profiles/rNN/
+                  counters_bench_<config>.json, matched on env, bins, memory order and the hash of the device code) —
+                  over the launch time measured live (HIP events on the launch stream), against 8 TB/s: `bound` "hbm",
+                  `achieved` / `peak` / `frac` (= `frac_hbm`), `traffic`, with the uncorrected `hbm_frac_raw` beside it.
+                  The x 2.0 is measured on the sweeps' own load shapes (tools/fetch_calibration.hip, profiles/r05/
+                  fetch_calibration.txt: every L2 read request moves a 128-B line and is tallied at 64 B).  These sweeps
+                  are a divergent gather plus 300-600 fp32 VALU instructions of dynamics per state and are NOT HBM-bound;
+                  `units` prices the two units that do limit them, each against its hardware peak, and
+                  `most_utilised_unit` names the busiest:
                     valu  wave64 VALU instructions/s against 1228.8 G/s (MI355X_MICROARCH.md: a wave64
                           fp32 instruction per 2 cycles per SIMD x 1024 SIMDs x 2.4 GHz).  The chip measures
                           ~950 G/s for fp32 fma/mul/add streams AND for mixes with compares / selects /
                           conversions up to 1:1, clustered or not (tools/valu_issue_bench.hip,
-                          profiles/r03/valu_issue.txt) — round 2's additive per-class model is withdrawn;
+                          profiles/r03/valu_issue.txt);
                     l1    the CU's vector-memory path: wave-wide vector loads/s (SQ_INSTS_VMEM_RD) against
                           CUs x clock / 16 = 38.4 G/s — a wave-wide 8- or 16-byte load occupies the path for
                           max(16, runs) cycles, a run being up to 4 consecutive lanes in one 128-B line
                           (tools/tcp_gather_bench.hip, profiles/r03/tcp_gather.txt), so 2^(D-1) corner-pair
                           loads per state need at least 16 x 2^(D-1) cycles per wave — 512 per 64 states in
-                          6-D; how long the TCP is clocked and how long it waits for L2 fills come with it
-                          (the raw TCP_TOTAL_CACHE_ACCESSES rate too, which is a count, not a utilisation);
-                    hbm   HBM-side bytes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) against 8 TB/s.
-                  `bound` names the unit with the highest utilisation, `achieved` / `peak` / `frac` are
-                  that unit's; `units` carries all three; `traffic` = the HBM-side bytes per launch.
+                          6-D; how long the TCP is clocked and how long it waits for L2 fills come with it;
+                    hbm   the headline unit again.
                   Everything that comes from the profile is withheld (null) when no committed profile
                   matches the config and the kernel version.
+  extra_configs — N = 1, default command: the other single-GPU BASELINE configs (C2 pendulum 200^2, C3 cartpole swing-up
+                  50^4, C5 double cartpole 25^6 and its 9-action swing-up variant) timed the same way after the headline —
+                  10 evaluation + 1 improvement sweeps per step from a synthetic resident state — each with its per-sweep
+                  times, whole-step throughput and roofline fractions; a compact copy sits in `roofline.extra_configs`.
+                  `--time-budget` (420 s) decides what is skipped when a box is slow: the run to convergence first.
   roofline_algorithmic — the SURVEY §8(d) byte model (89 B per 4-D evaluation backup) over the
                   launch time, for reference only: those bytes are cache hits, not a bound.
   sweeps_to_converge — a full run() of policy iteration from V = 0 with the env's own settings (N = 1,
@@ -82,11 +89,16 @@ from pathlib import Path
 
 import numpy as np
 
+T_PROCESS_START = time.perf_counter()
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# FETCH_SIZE tallies every L2 read request at 64 B while the request moves a 128-B line — measured on the sweeps' own
+# access shapes (overlapping 4-byte-aligned 8-byte pairs, 4- and 1-byte non-temporal streams, lone 8-byte loads per line:
+# factor 1.97-2.00 on every one; tools/fetch_calibration.hip, profiles/r05/fetch_calibration.txt).  WRITE_SIZE is exact.
+FETCH_CORRECTION = 2.0
 VALU_PEAK_GIPS = 256 * 4 * 2.4 / 2.0     # wave64 fp32 VALU instructions/s: 2 cycles each per SIMD-32
 VALU_MEASURED_GIPS = 950.0               # what the chip sustains for fp32 and mixed streams (profiles/r03/valu_issue.txt)
 # Vector L1 (TCP / TA).  Every wave-wide 8- or 16-byte load occupies the CU's vector-memory path for at least 16 cycles
@@ -203,6 +215,104 @@ def numpy_reference_c1() -> dict:
             "config": "Pendulum 50 x 50 x 11 actions, numpy float32, one thread"}
 
 
+def kernel_units(name, ms, backups, alg_bytes_per_backup, *, prof, prof_scale, n, n_live, live_per_launch,
+                 states_per_launch, counters=None):
+    """Timing of one kernel plus, when a matching profile exists, the utilisation of the three
+    units it can be bound by (VALU issue, vector-L1 tag look-ups, HBM)."""
+    sec = ms * 1e-3
+    e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups, "backups_per_s": backups / sec}
+    if n_live != n:
+        e["backups_per_launch_live"] = int(round(backups * live_per_launch / float(states_per_launch)))
+        e["backups_per_s_live"] = e["backups_per_launch_live"] / sec
+    alg = alg_bytes_per_backup * backups / sec / 1e9
+    e["algorithmic"] = {"bytes_per_backup": alg_bytes_per_backup, "achieved_GBps": alg,
+                        "note": "SURVEY 8(d) byte model; served by L1/L2/Infinity Cache, not a bound"}
+    k = ((prof or {}).get("kernels", {}) if counters is None else counters).get(name)
+    if not k or "valu_insts_per_wave" not in k:
+        return e
+    c = k["counters"]
+    waves = c["SQ_WAVES"] * prof_scale
+    units = {}
+    insts = k["valu_insts_per_wave"] * waves
+    ach = insts / sec / 1e9
+    units["valu"] = {"achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s",
+                     "frac": ach / VALU_PEAK_GIPS, "frac_of_measured_peak": ach / VALU_MEASURED_GIPS,
+                     "measured_peak": VALU_MEASURED_GIPS, "insts_per_wave": k["valu_insts_per_wave"],
+                     "waves_per_launch": waves, "class_split_per_wave": k.get("issue_cycles_model")}
+    acc, req = c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), c.get("TCP_TCC_READ_REQ_sum")
+    acc, req = (None if acc is None else acc * prof_scale), (None if req is None else req * prof_scale)
+    loads = (k.get("vmem_rd_insts_per_wave") or 0.0) * waves
+    if loads:
+        ach = loads / sec / 1e9
+        tcp = k.get("tcp_per_cu_cycle") or {}
+        units["l1"] = {"achieved": ach, "peak": TCP_PEAK_GLOADS, "unit": "G wave-wide vector loads/s",
+                       "frac": ach / TCP_PEAK_GLOADS, "loads_per_wave": k.get("vmem_rd_insts_per_wave"),
+                       "loads_per_launch": loads,
+                       "accesses_per_launch": acc, "l2_served_lines_per_launch": req,
+                       "accesses_per_cu_cycle": None if not acc else acc / sec / 1e9 / (256 * 2.4),
+                       "l1_hit_rate": k.get("l1_hit_rate"),
+                       "tcp_clocked_frac": tcp.get("TCP_GATE_EN1_sum"),
+                       "tcp_waiting_for_l2_frac": tcp.get("TCP_PENDING_STALL_CYCLES_sum"),
+                       "note": "frac = 16 cycles x vector loads per CU / launch cycles at 2.4 GHz: the share of the "
+                               "launch the vector-memory path needs at the very least (4 lanes per cycle; loads "
+                               "whose lanes fall into more than 16 runs need more, 1- and 4-byte loads less).  "
+                               "tcp_clocked / waiting_for_l2: share of the launch the TCP is clocked / stalled on "
+                               "L2 fills (same profile).  accesses_per_cu_cycle is the raw counter, not a "
+                               "utilisation (profiles/r03/tcp_gather.txt)"}
+    if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
+        traffic = (FETCH_CORRECTION * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]) * prof_scale
+        raw = (k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]) * prof_scale
+        units["hbm"] = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": traffic / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
+                        "frac_raw": raw / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_launch_raw": raw,
+                        "fetch_bytes_counted": k["FETCH_SIZE_bytes"] * prof_scale, "write_bytes": k["WRITE_SIZE_bytes"] * prof_scale,
+                        "l2_hit_rate": k.get("l2_hit_rate")}
+    e["units"] = units
+    gui, prof_ms = c.get("GRBM_GUI_ACTIVE"), k.get("ms_under_profiler")
+    if gui and prof_ms:
+        e["clock_GHz_under_profiler"] = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # summed over the 8 XCDs
+    return e
+
+
+def build_roofline(dom: dict, khash: str, prof_path, compulsory_per_state: float, compulsory: float, prof_scale=None) -> dict:
+    """The `roofline` object of the line for the dominant kernel `dom` (a kernel_units entry).  The headline fraction is
+    the one the north star names — measured HBM-side bytes per launch (rocprofv3 FETCH_SIZE x the calibrated 2.0 +
+    WRITE_SIZE, committed profile of this kernel version) over the launch time measured live, against 8 TB/s — with the
+    uncorrected figure and the two other units the kernel can be bound by (VALU issue, vector-load issue) beside it."""
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "frac_hbm": None, "hbm_frac_raw": None, "traffic": None, "traffic_raw": None,
+                "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash, "profile": prof_path,
+                "profile_scaled_to_rank_share": prof_scale,
+                "compulsory_bytes_per_state": compulsory_per_state,
+                "fetch_correction": {"factor": FETCH_CORRECTION, "source": "profiles/r05/fetch_calibration.txt",
+                                     "note": "every L2 read request moves a 128-B line and is tallied at 64 B: measured "
+                                             "1.97-2.00 on the sweeps' own load shapes; WRITE_SIZE exact; Infinity-Cache "
+                                             "hits are counted, so `traffic` is an upper bound of what reaches HBM"},
+                "peak_source": "MI355X_MICROARCH.md: HBM3E 8 TB/s; VALU 1228.8 G wave64 instr/s (2 cycles x 1024 SIMDs x "
+                               "2.4 GHz); vector-memory path one wave-wide load per 16 cycles per CU = 38.4 G/s"}
+    units = dom.get("units")
+    if units:
+        roofline["units"] = units
+        roofline["clock_GHz_under_profiler"] = dom.get("clock_GHz_under_profiler")
+        name = max(units, key=lambda u: units[u]["frac"])
+        roofline["most_utilised_unit"] = {"name": {"valu": "valu-issue", "l1": "l1-load-issue", "hbm": "hbm"}[name],
+                                          "frac": units[name]["frac"], "achieved": units[name]["achieved"],
+                                          "peak": units[name]["peak"], "unit": units[name]["unit"]}
+        if "hbm" in units:
+            h = units["hbm"]
+            roofline.update({"achieved": h["achieved"], "frac": h["frac"], "frac_hbm": h["frac"], "hbm_frac": h["frac"],
+                             "hbm_frac_raw": h["frac_raw"], "traffic": h["bytes_per_launch"],
+                             "traffic_raw": h["bytes_per_launch_raw"],
+                             "traffic_vs_compulsory": h["bytes_per_launch"] / compulsory,
+                             "traffic_vs_compulsory_raw": h["bytes_per_launch_raw"] / compulsory})
+            roofline["north_star_target"] = {
+                "hbm_frac_at_least_0.40": bool(h["frac"] >= 0.40),
+                "note": "not an HBM-bound kernel: the sweep is co-limited by wave latency, VALU issue and vector-load "
+                        "issue (units); at its instruction count the VALU-issue floor alone is at or above the time "
+                        "40 % of HBM would allow (DESIGN.md section 4)"}
+    return roofline
+
+
 def load_profile(env: str, bins: int, n_states: int, kernel_hash: str, label: str = "bench", order=None):
     """Latest committed PMC profile (tools/profile_config.sh) of this config — env, bins, memory order of the
     dimensions — on the bench (or policy-iteration: label "real") state whose kernel hash is the current one."""
@@ -218,6 +328,99 @@ def load_profile(env: str, bins: int, n_states: int, kernel_hash: str, label: st
         if prof.get("env", ENV) == env and prof.get("bins", BINS) == bins:
             return prof, str(path.relative_to(ROOT))
     return None, None
+
+
+# The other single-GPU BASELINE configs, timed by the same default command after the headline (N = 1 only):
+# (label, env, bins, timed steps, warm-up steps).  One step = 10 evaluation sweeps + 1 improvement sweep, as the headline's.
+EXTRA_CONFIGS = [
+    ("c2", "pendulum", 200, 200, 20),
+    ("c3", "cartpole_swingup", 50, 40, 5),
+    ("c5", "double_cartpole", 25, 4, 1),
+    ("c5_swingup", "double_cartpole_swingup", 25, 2, 1),
+]
+# rough wall seconds an extra config needs on a GPU box (construction incl. the terminal hook and the live list, the
+# timed steps, the state transfer): what the time budget is checked against before it starts
+EXTRA_COST_S = {"c2": 6.0, "c3": 8.0, "c5": 60.0, "c5_swingup": 60.0}
+
+
+def measure_extra_config(label: str, env: str, bins: int, steps: int, warmup: int, dev, khash: str) -> dict:
+    """10 evaluation sweeps + 1 improvement sweep of one more BASELINE config through the product path (solver -> C ABI ->
+    HIP), from the same kind of synthetic resident state as the headline: per-sweep times (HIP events on the launch
+    stream), whole-step throughput, and the roofline units from the committed profile of this kernel version."""
+    import torch
+    from dynamicprogramming_amd import envs
+    t_wall = time.perf_counter()
+    cls = envs.ENVS[env]
+    solver = envs.make(env, bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
+    n, nA, D = solver.n_states, solver.n_actions, cls._D
+    gamma = float(np.float32(solver.config.gamma))
+    eng = solver._backend.engine
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    solver.d_value_function[:n].copy_(torch.randn(n, generator=gen, dtype=torch.float32))
+    solver.d_new_value_function.copy_(solver.d_value_function)
+    solver.d_policy[:n].copy_(torch.randint(0, nA, (n,), generator=gen, dtype=torch.int32))
+    n_live = n - int(solver.d_terminal_mask[:n].sum().item())
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        solver._evaluation_sweeps(EVAL_PER_STEP, gamma)
+        if k is not None:
+            ev[k][1].record()
+        solver._improvement_sweep(gamma)
+        if k is not None:
+            ev[k][2].record()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eval_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) / EVAL_PER_STEP
+    improve_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / IMPROVE_PER_STEP
+    live_states = eng.info(16)
+    dominant, dom_ms = ("pi_eval_sweep_kernel", eval_ms)
+    if live_states > 0:                    # later sweeps of a batch run over the live-state list: their own launch time
+        def batch_ms(k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            solver._evaluation_sweeps(k, gamma)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        batch_ms(2)
+        first_ms = min(batch_ms(1) for _ in range(2))
+        dominant, dom_ms = "pi_eval_live_kernel", (min(batch_ms(11) for _ in range(2)) - first_ms) / 10.0
+    backups_per_step = n * (EVAL_PER_STEP + IMPROVE_PER_STEP * nA)
+    prof, prof_path = load_profile(env, bins, n, khash, order=eng.order)
+    compulsory_per_state = 12.0 if solver._mask_arg() is None else 13.0
+    entry = kernel_units(dominant, dom_ms, n, algorithmic_bytes_eval(D), prof=prof, prof_scale=1.0, n=n, n_live=n_live,
+                         live_per_launch=n_live, states_per_launch=n)
+    roof = build_roofline(entry, khash, prof_path, compulsory_per_state, compulsory_per_state * n)
+    units = roof.get("units") or {}
+    out = {"label": label, "workload": f"{env} {D}D grid bins={bins}/dim ({n} states) x {nA} actions, gamma={solver.config.gamma}; "
+                                       f"step = {EVAL_PER_STEP} eval sweeps + {IMPROVE_PER_STEP} improve sweep",
+           "env": env, "bins": bins, "states": n, "nonterminal_states": n_live, "actions": nA, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "eval_ms": eval_ms, "improve_ms": improve_ms,
+           "backups_per_s": backups_per_step * steps / elapsed,
+           "backups_per_s_nonterminal": n_live * (EVAL_PER_STEP + IMPROVE_PER_STEP * nA) * steps / elapsed,
+           "memory_order": list(eng.order),
+           "roofline": {"kernel": dominant, "avg_launch_ms": dom_ms, "frac_hbm": roof.get("frac_hbm"),
+                        "hbm_frac_raw": roof.get("hbm_frac_raw"), "traffic_vs_compulsory": roof.get("traffic_vs_compulsory"),
+                        "valu_frac": (units.get("valu") or {}).get("frac"), "l1_load_issue_frac": (units.get("l1") or {}).get("frac"),
+                        "most_utilised_unit": roof.get("most_utilised_unit"), "profile": prof_path},
+           "check": {"last_residual": float(solver._d_delta.item()), "last_changed": int(solver._d_changed.item()),
+                     "live_list_states": live_states},
+           "wall_seconds": None}
+    solver._backend.close()
+    del solver
+    torch.cuda.empty_cache()
+    out["wall_seconds"] = time.perf_counter() - t_wall
+    return out
 
 
 def launch_command(n_gpus: int, argv: list[str], port: int | None = None) -> list[str]:
@@ -246,8 +449,8 @@ ATTEMPT_TIMEOUT = 240.0
 # After the first rung that succeeds, the SAME exchange runs once more over the library's peer-to-peer transport
 # (csrc/pi_p2p.cpp: halo rows stored straight into IPC-mapped peer buffers, no RCCL) in fresh processes, best effort: its
 # figures are attached to the line as check.exchange.p2p and its failure costs nothing but its time limit.  Both runs check
-# their sharded sweeps against the unsharded ones bit for bit before AND after the timed region; the line reports the faster
-# of the two as `value` and both under `value_by_transport`.
+# their sharded sweeps against the unsharded ones bit for bit before AND after the timed region; `value` stays the primary
+# (RCCL) rung's — the transport chosen up front — and both figures stand under `value_by_transport`.
 BONUS_P2P = {"PI_MI355_TRANSPORT": "p2p", "PI_MI355_COMM_TIMEOUT": "30", "PI_BENCH_BONUS": "1"}
 BONUS_TIMEOUT = 150.0
 # ... and when NO RCCL rung works (a broken RCCL installation is not a reason to report nothing), the peer-to-peer transport
@@ -313,6 +516,19 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
         bonus_p2p = False
     ladder = LADDER if ladder is None else ladder
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # The worker of the current rung lives in a session of its own (so that it can be killed with everything it started):
+    # nobody else reaps it.  SIGTERM / SIGINT — the launcher tearing the remaining ranks down after one supervisor died,
+    # self_launch killing the launcher's process group on overrun — end it first, then this supervisor exits non-zero.
+    import signal
+    current: dict = {"proc": None}
+
+    def _reap_and_exit(signum, _frame):
+        if current["proc"] is not None:
+            kill_process_group(current["proc"], grace=2.0)
+        os._exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, _reap_and_exit)
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=attempt_timeout * len(ladder) + BONUS_TIMEOUT + 300))
     attempts, line = [], None
     try:
@@ -328,24 +544,31 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             proc = subprocess.Popen(worker_command(argv), env=env, text=True, start_new_session=True,
                                     stdout=subprocess.PIPE if rank == 0 else sys.stderr)
+            current["proc"] = proc                                # what the signal handler and the finally below reap
             chunks: list[str] = []
             reader = None
             if rank == 0:
                 reader = threading.Thread(target=lambda: chunks.append(proc.stdout.read()), daemon=True)
                 reader.start()
             t0 = time.monotonic()
-            while True:
-                rc = proc.poll()
-                flags = torch.tensor([int(rc not in (None, 0)), int(rc == 0), int(time.monotonic() - t0 > limit)],
-                                     dtype=torch.int32)
-                dist.all_reduce(flags)                            # the same verdict on every rank, twice a second
-                failed, done, late = (int(v) for v in flags.tolist())
-                if failed or late or done == world:
-                    break
-                time.sleep(0.5)
-            ok = done == world and not failed
-            if not ok:
-                kill_process_group(proc)
+            ok = False
+            try:
+                while True:
+                    rc = proc.poll()
+                    flags = torch.tensor([int(rc not in (None, 0)), int(rc == 0), int(time.monotonic() - t0 > limit)],
+                                         dtype=torch.int32)
+                    dist.all_reduce(flags)                        # the same verdict on every rank, twice a second
+                    failed, done, late = (int(v) for v in flags.tolist())
+                    if failed or late or done == world:
+                        break
+                    time.sleep(0.5)
+                ok = done == world and not failed
+            finally:
+                # a worker never outlives its rung: not when the rung failed or ran late, and not when a collective above
+                # raised because a peer supervisor died or timed out (the worker would sit in an RCCL collective for
+                # minutes and poison the next run on the box)
+                if not ok:
+                    kill_process_group(proc)
             if reader is not None:
                 reader.join(timeout=10.0)
             codes = [None] * world
@@ -390,32 +613,12 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
                 obj["check"]["exchange"] = {}
             if bonus is not None:
                 obj["check"]["exchange"]["p2p"] = bonus
-            # Both transports ran the same workload under the same contract in this run, each checked bit for bit against the
-            # unsharded sweeps before and after its timed region: the line reports the FASTER one as `value` and keeps the
-            # other's figures beside it (`value_by_transport`, check.exchange.rccl / .p2p).
-            try:
-                if bonus_obj is not None and float(bonus_obj["value"]) > float(obj["value"]):
-                    x1 = obj["check"]["exchange"]
-                    summary = {"value": obj.get("value"), "ms_per_step": obj.get("ms_per_step"), "transport": x1.get("transport"),
-                               "bit_identical": x1.get("bit_identical"), "eval_ms_max": x1.get("eval_ms_max"),
-                               "eval_ms_min": x1.get("eval_ms_min"), "per_rank": x1.get("per_rank"), "plan_mode": x1.get("mode"),
-                               "ladder_mode": x1.get("ladder_mode")}
-                    chosen = bonus_obj
-                    chosen.setdefault("check", {})
-                    if not isinstance(chosen["check"].get("exchange"), dict):
-                        chosen["check"]["exchange"] = {}
-                    chosen["check"]["exchange"]["rccl"] = summary
-                    chosen["check"]["exchange"]["p2p"] = {k_: v for k_, v in bonus.items() if k_ not in ("per_rank",)}
-                    if "cpu_baseline" in obj and "cpu_baseline" not in chosen:
-                        chosen["cpu_baseline"] = obj["cpu_baseline"]        # a property of the box, measured once
-                    chosen["value_by_transport"] = {"rccl": obj.get("value"), "p2p": bonus_obj.get("value"),
-                                                    "reported": "p2p (the faster of the two, both measured in this run)"}
-                    obj = chosen
-                elif bonus_obj is not None:
-                    obj["value_by_transport"] = {"rccl": obj.get("value"), "p2p": bonus_obj.get("value"),
-                                                 "reported": "rccl (the faster of the two, both measured in this run)"}
-            except Exception as exc:  # noqa: BLE001 - never lose the measured line over the comparison
-                obj["check"]["exchange"]["transport_choice_error"] = repr(exc)
+            # `value` is the rung that succeeded FIRST — the transport chosen up front (RCCL unless every RCCL rung failed).
+            # The best-effort rerun over the peer-to-peer transport is reported beside it and never replaces it: picking
+            # the faster of two runs after the fact would bias the metric upward.
+            if bonus_obj is not None:
+                obj["value_by_transport"] = {"rccl": obj.get("value"), "p2p": bonus_obj.get("value"),
+                                             "reported": "rccl (the primary rung; the p2p figure is a best-effort rerun)"}
             obj["check"]["exchange"]["attempts"] = attempts
             print(json.dumps(obj), flush=True)
         success = bool(attempts and attempts[-1]["ok"])
@@ -423,6 +626,8 @@ def supervise(argv: list[str], attempt_timeout: float = ATTEMPT_TIMEOUT, ladder=
             print(f"bench.py: every rung of the ladder failed: {json.dumps(attempts)}", file=sys.stderr, flush=True)
         return 0 if success else 1
     finally:
+        if current["proc"] is not None:
+            kill_process_group(current["proc"])                   # no-op for a worker that has exited
         dist.destroy_process_group()
 
 
@@ -480,10 +685,17 @@ def share_gpu() -> bool:
     return os.environ.get("PI_BENCH_SHARE_GPU") == "1"
 
 
+def over_p2p() -> bool:
+    """This rank's exchange runs over the library's peer-to-peer transport (the rehearsal, the best-effort rerun, and the
+    ladder's last rung — the one that is left when RCCL itself is what fails): torch.distributed then runs over gloo and its
+    small tensors live on the host, so that nothing in the process creates an RCCL communicator."""
+    return share_gpu() or os.environ.get("PI_MI355_TRANSPORT", "").lower() == "p2p"
+
+
 def _collective_device(dev):
     """Where the small tensors of torch.distributed collectives live: on the GPU under RCCL, on the host under gloo."""
     import torch
-    return torch.device("cpu") if share_gpu() else dev
+    return torch.device("cpu") if over_p2p() else dev
 
 
 def sharded_equals_unsharded(solver, eng, gamma, torch, dist, n_eval: int = 2, gather_first: bool = False) -> dict:
@@ -548,6 +760,12 @@ def main() -> None:
                     help="states of the same grid the all-core CPU baseline sweeps, taken with a uniform "
                          "stride over the whole grid (default: all of the 80^4 grid, ~6 s on 16 threads; "
                          "the 1-thread run takes every 16th of those)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1, default config only: skip the other single-GPU BASELINE configs (C2, C3, C5, C5 swing-up) "
+                         "that are timed after the headline and reported under `extra_configs`")
+    ap.add_argument("--time-budget", type=float, default=420.0,
+                    help="wall seconds the whole default run may take: optional parts that would not fit are skipped — the "
+                         "run to convergence first, then extra configs — and say so in the line")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="with --gpus N > 1 outside torch.distributed.run: print the child command that "
                          "would start the N ranks and the fallback ladder, and exit")
@@ -580,7 +798,8 @@ def main() -> None:
     if world > 1:
         if share_gpu():
             os.environ["PI_MI355_TRANSPORT"] = "p2p"
-            dist.init_process_group("gloo")
+        if over_p2p():
+            dist.init_process_group("gloo")               # no RCCL anywhere in this process (P2pTransport gathers on any backend)
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -717,10 +936,32 @@ def main() -> None:
                      "policy = 0 with at most 2000 evaluation sweeps each", "prepare_seconds": t_prep,
                      "residual": float(solver._d_delta.item())}
 
+    # ── the other single-GPU BASELINE configs on the same clock (N = 1, default config only) ──────────────
+    khash = _native.kernel_source_hash()
+    t_start = T_PROCESS_START
+    extra_configs, extra_skipped = [], []
+    full_run_cost = 45.0 if (args.env, args.bins) == (ENV, BINS) else 0.0
+    cpu_cost = 0.0 if args.no_cpu_baseline else 25.0
+    if world == 1 and not args.no_extra_configs and (args.env, args.bins) == (ENV, BINS):
+        # the headline's device arrays are not needed while the extras run (25^6 wants ~4 GB): keep them, 288 GB is plenty
+        for label, x_env, x_bins, x_steps, x_warm in EXTRA_CONFIGS:
+            spent = time.perf_counter() - t_start
+            if spent + EXTRA_COST_S[label] + cpu_cost > args.time_budget:
+                extra_skipped.append({"label": label, "reason": f"time budget: {spent:.0f} s spent of {args.time_budget:.0f}"})
+                continue
+            try:
+                extra_configs.append(measure_extra_config(label, x_env, x_bins, x_steps, x_warm, dev, khash))
+            except Exception as exc:                  # never lose the headline over an extra
+                extra_skipped.append({"label": label, "reason": repr(exc)})
+
     # ── sweeps-to-converge (optional: a full run() from V = 0 with the env's own settings) ───
     full_run = None
     if world == 1 and not args.no_full_run and n >= (1 << 27) and not args.full_run:
         full_run = {"skipped": f"{n} states: a run to convergence takes minutes; pass --full-run"}
+    elif (world == 1 and not args.no_full_run and not args.full_run
+          and time.perf_counter() - t_start + full_run_cost + cpu_cost > args.time_budget):
+        full_run = {"skipped": f"time budget: {time.perf_counter() - t_start:.0f} s spent of {args.time_budget:.0f}; "
+                               f"pass --full-run (profiles/r05/full_runs.txt holds the measured runs)"}
     elif world == 1 and not args.no_full_run:
         try:
             fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
@@ -739,7 +980,6 @@ def main() -> None:
             full_run = {"error": repr(exc)}
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
-    khash = _native.kernel_source_hash()
     prof, prof_path = (None, None) if minimal else load_profile(args.env, args.bins, n, khash, order=eng.order)
     # N > 1: the committed profile is the single-GPU launch of the same kernel; per-wave figures carry over, the number
     # of waves (and every per-launch total) scales with this rank's share of the states
@@ -752,58 +992,8 @@ def main() -> None:
     compulsory = compulsory_per_state * states_per_launch
 
     def kernel_entry(name, ms, backups, alg_bytes_per_backup, counters=None):
-        """Timing of one kernel plus, when a matching profile exists, the utilisation of the three
-        units it can be bound by (VALU issue, vector-L1 tag look-ups, HBM)."""
-        sec = ms * 1e-3
-        e = {"kernel": name, "avg_launch_ms": ms, "backups_per_launch": backups, "backups_per_s": backups / sec}
-        if n_live != n:
-            e["backups_per_launch_live"] = int(round(backups * live_per_launch / float(states_per_launch)))
-            e["backups_per_s_live"] = e["backups_per_launch_live"] / sec
-        alg = alg_bytes_per_backup * backups / sec / 1e9
-        e["algorithmic"] = {"bytes_per_backup": alg_bytes_per_backup, "achieved_GBps": alg,
-                            "note": "SURVEY 8(d) byte model; served by L1/L2/Infinity Cache, not a bound"}
-        k = ((prof or {}).get("kernels", {}) if counters is None else counters).get(name)
-        if not k or "valu_insts_per_wave" not in k:
-            return e
-        c = k["counters"]
-        waves = c["SQ_WAVES"] * prof_scale
-        units = {}
-        insts = k["valu_insts_per_wave"] * waves
-        ach = insts / sec / 1e9
-        units["valu"] = {"achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s",
-                         "frac": ach / VALU_PEAK_GIPS, "frac_of_measured_peak": ach / VALU_MEASURED_GIPS,
-                         "measured_peak": VALU_MEASURED_GIPS, "insts_per_wave": k["valu_insts_per_wave"],
-                         "waves_per_launch": waves, "class_split_per_wave": k.get("issue_cycles_model")}
-        acc, req = c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), c.get("TCP_TCC_READ_REQ_sum")
-        acc, req = (None if acc is None else acc * prof_scale), (None if req is None else req * prof_scale)
-        loads = (k.get("vmem_rd_insts_per_wave") or 0.0) * waves
-        if loads:
-            ach = loads / sec / 1e9
-            tcp = k.get("tcp_per_cu_cycle") or {}
-            units["l1"] = {"achieved": ach, "peak": TCP_PEAK_GLOADS, "unit": "G wave-wide vector loads/s",
-                           "frac": ach / TCP_PEAK_GLOADS, "loads_per_wave": k.get("vmem_rd_insts_per_wave"),
-                           "loads_per_launch": loads,
-                           "accesses_per_launch": acc, "l2_served_lines_per_launch": req,
-                           "accesses_per_cu_cycle": None if not acc else acc / sec / 1e9 / (256 * 2.4),
-                           "l1_hit_rate": k.get("l1_hit_rate"),
-                           "tcp_clocked_frac": tcp.get("TCP_GATE_EN1_sum"),
-                           "tcp_waiting_for_l2_frac": tcp.get("TCP_PENDING_STALL_CYCLES_sum"),
-                           "note": "frac = 16 cycles x vector loads per CU / launch cycles at 2.4 GHz: the share of the "
-                                   "launch the vector-memory path needs at the very least (4 lanes per cycle; loads "
-                                   "whose lanes fall into more than 16 runs need more, 1- and 4-byte loads less).  "
-                                   "tcp_clocked / waiting_for_l2: share of the launch the TCP is clocked / stalled on "
-                                   "L2 fills (same profile).  accesses_per_cu_cycle is the raw counter, not a "
-                                   "utilisation (profiles/r03/tcp_gather.txt)"}
-        if "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k:
-            traffic = (2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]) * prof_scale
-            units["hbm"] = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": traffic / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
-                            "l2_hit_rate": k.get("l2_hit_rate")}
-        e["units"] = units
-        gui, prof_ms = c.get("GRBM_GUI_ACTIVE"), k.get("ms_under_profiler")
-        if gui and prof_ms:
-            e["clock_GHz_under_profiler"] = gui / 8.0 / (prof_ms * 1e-3) / 1e9      # summed over the 8 XCDs
-        return e
+        return kernel_units(name, ms, backups, alg_bytes_per_backup, prof=prof, prof_scale=prof_scale, n=n, n_live=n_live,
+                            live_per_launch=live_per_launch, states_per_launch=states_per_launch, counters=counters)
 
     if live_states > 0:
         kernels = {
@@ -829,32 +1019,14 @@ def main() -> None:
         kernels["eval_converged_policy"] = converged
     share = {"eval_sweeps": eval_ms * EVAL_PER_STEP, "improve_sweep": improve_ms * IMPROVE_PER_STEP}
     dom = kernels["eval_sweep"] if share["eval_sweeps"] >= share["improve_sweep"] else kernels["improve_sweep"]
-    roofline = {"bound": None, "kernel": dom["kernel"], "achieved": None, "peak": None, "unit": None, "frac": None,
-                "traffic": None, "avg_launch_ms": dom["avg_launch_ms"], "kernel_source_hash": khash,
-                "profile": prof_path,
-                "profile_scaled_to_rank_share": None if world == 1 else prof_scale,
-                "compulsory_bytes_per_state": compulsory_per_state,
-                "vmem_rd_note": "vector loads per wave of two chunks = 16 corner-pair loads + 2 policy loads + 7/16 (the "
-                                "table-staging load is exec-masked: 411 table floats, so 7 of a workgroup's 16 waves issue "
-                                "it) + 2 old-value loads on the 1 sweep in 25..50 that reports a residual",
-                "peak_source": "MI355X_MICROARCH.md: VALU 1228.8 G wave64 instr/s (2 cycles x 1024 SIMDs x 2.4 GHz); "
-                               "vector L1 one tag look-up per CU and cycle = 614.4 G/s; HBM3E 8 TB/s"}
-    units = dom.get("units")
-    if units:
-        name = max(units, key=lambda u: units[u]["frac"])
-        roofline.update({"bound": {"valu": "valu-issue", "l1": "l1-load-issue", "hbm": "hbm"}[name],
-                         "achieved": units[name]["achieved"], "peak": units[name]["peak"],
-                         "unit": units[name]["unit"], "frac": units[name]["frac"], "units": units,
-                         "clock_GHz_under_profiler": dom.get("clock_GHz_under_profiler")})
-        if "hbm" in units:
-            roofline["traffic"] = units["hbm"]["bytes_per_launch"]
-            roofline["traffic_vs_compulsory"] = units["hbm"]["bytes_per_launch"] / compulsory
-            roofline["hbm_frac"] = units["hbm"]["frac"]
+    roofline = build_roofline(dom, khash, prof_path, compulsory_per_state, compulsory, None if world == 1 else prof_scale)
     alg_gbps = dom["algorithmic"]["achieved_GBps"]
     roofline_algorithmic = {"bound": "hbm", "kernel": dom["kernel"], "achieved": alg_gbps, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": None, "bytes_per_backup": dom["algorithmic"]["bytes_per_backup"],
-                            "note": "algorithmic bytes are cache hits here; the measured HBM-side traffic is "
-                                    "roofline.traffic — no fraction is quoted against this model"}
+                            "unit": "GB/s", "frac": None, "ratio_to_hbm_peak": alg_gbps / HBM_PEAK_GBS,
+                            "bytes_per_backup": dom["algorithmic"]["bytes_per_backup"],
+                            "note": "SURVEY 8(d)'s algorithmic bytes over the launch time: above the HBM peak because the 2^D "
+                                    "corner reads are L1 / L2 / Infinity-Cache hits; not a bound, no fraction is claimed "
+                                    "against it — the measured HBM-side fraction is roofline.frac"}
 
     exchange = None
     if solver._comm is not None and getattr(solver._comm, "info", None) and minimal:
@@ -915,6 +1087,8 @@ def main() -> None:
         "kernels": kernels,
         "time_share_ms": share,
         "sweeps_to_converge": full_run,
+        "extra_configs": extra_configs,
+        "extra_configs_skipped": extra_skipped,
         "eval_backups_per_s": states_per_launch * world / (eval_ms * 1e-3),
         "improve_backups_per_s": states_per_launch * world * nA / (improve_ms * 1e-3),
         "check": {"last_residual": last_delta, "last_changed": last_changed,
@@ -927,10 +1101,21 @@ def main() -> None:
                                            "host-side arrays and all arithmetic stay in the env's own order"},
                   "exchange": exchange},
     }
+    if extra_configs:
+        out["roofline"]["extra_configs"] = {
+            x["label"]: {"env": x["env"], "bins": x["bins"], "eval_ms": round(x["eval_ms"], 5), "improve_ms": round(x["improve_ms"], 5),
+                         "backups_per_s": float(f"{x['backups_per_s']:.4g}"), "frac_hbm": x["roofline"]["frac_hbm"],
+                         "hbm_frac_raw": x["roofline"]["hbm_frac_raw"], "valu_frac": x["roofline"]["valu_frac"],
+                         "l1_load_issue_frac": x["roofline"]["l1_load_issue_frac"]} for x in extra_configs}
     if rank == 0 and not args.no_cpu_baseline and not minimal and os.environ.get("PI_BENCH_BONUS") != "1":   # rank 0's host cores; the other ranks wait at the barrier below
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if extra_configs or extra_skipped:       # and in short on stderr, where a truncated log still shows it
+            brief = [f"{x['label']}: eval {x['eval_ms']:.4f} ms, improve {x['improve_ms']:.4f} ms, {x['backups_per_s']:.3e} backups/s, "
+                     f"frac_hbm {x['roofline']['frac_hbm']}" for x in extra_configs]
+            print("bench.py extra_configs | " + " | ".join(brief + [f"{x['label']}: skipped ({x['reason']})" for x in extra_skipped]),
+                  file=sys.stderr, flush=True)
     if world > 1:
         # tear down in a defined order: drain the GPU, let every rank arrive, destroy the library's
         # RCCL communicator (it dies with the engine handle), then torch's process group

@@ -127,22 +127,20 @@ def test_supervisors_relay_the_first_rung_when_it_works():
     assert p2p["ok"] is True and p2p["mode"] == "halo+overlap over p2p" and p2p["value"] == 1.0
 
 
-def test_the_faster_transport_is_reported_and_the_other_kept_beside_it(monkeypatch):
-    monkeypatch.setenv("FAKE_P2P_VALUE", "3.5")
-    (_, rc0, out0), (_, rc1, _) = _run_supervisors([["ok", "ok"]])
-    assert (rc0, rc1) == (0, 0)
-    (line,) = out0.strip().splitlines()
-    obj = json.loads(line)
-    assert obj["value"] == 3.5 and obj["value_by_transport"] == {
-        "rccl": 1.0, "p2p": 3.5, "reported": "p2p (the faster of the two, both measured in this run)"}
-    x = obj["check"]["exchange"]
-    assert x["mode"] == "halo+overlap over p2p" and x["rccl"]["value"] == 1.0 and x["p2p"]["ok"] is True
-    assert [a["mode"] for a in x["attempts"]] == ["halo+overlap"]
-    monkeypatch.setenv("FAKE_P2P_VALUE", "0.5")
-    (_, rc0, out0), _ = _run_supervisors([["ok", "ok"]])
-    obj = json.loads(out0.strip().splitlines()[-1])
-    assert obj["value"] == 1.0 and obj["value_by_transport"]["reported"].startswith("rccl")
-    assert obj["check"]["exchange"]["p2p"]["value"] == 0.5
+def test_value_is_the_primary_rung_and_the_p2p_rerun_stands_beside_it(monkeypatch):
+    """`value` is the transport chosen up front (the first rung that works); a faster best-effort rerun over the
+    peer-to-peer transport is reported under value_by_transport / check.exchange.p2p and never replaces it."""
+    for p2p_value in ("3.5", "0.5"):
+        monkeypatch.setenv("FAKE_P2P_VALUE", p2p_value)
+        (_, rc0, out0), (_, rc1, _) = _run_supervisors([["ok", "ok"]])
+        assert (rc0, rc1) == (0, 0)
+        (line,) = out0.strip().splitlines()
+        obj = json.loads(line)
+        assert obj["value"] == 1.0 and obj["value_by_transport"]["rccl"] == 1.0
+        assert obj["value_by_transport"]["p2p"] == float(p2p_value) and obj["value_by_transport"]["reported"].startswith("rccl")
+        x = obj["check"]["exchange"]
+        assert x["mode"] == "halo+overlap" and x["p2p"]["ok"] is True and x["p2p"]["value"] == float(p2p_value)
+        assert [a["mode"] for a in x["attempts"]] == ["halo+overlap"]
 
 
 def test_a_failing_p2p_rerun_costs_nothing():
@@ -281,3 +279,67 @@ def test_the_minimal_rung_is_the_last_resort():
     att = json.loads(out0.strip().splitlines()[-1])["check"]["exchange"]["attempts"]
     assert [a["mode"] for a in att] == ["halo+overlap", "halo", "allgather", "allgather-minimal"]
     assert [a["ok"] for a in att] == [False, False, False, True]
+
+
+SIGNALLED_SUPERVISOR = r"""
+import importlib.util, os, sys
+spec = importlib.util.spec_from_file_location('bench_under_test', sys.argv[1])
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+marker = sys.argv[2]
+child = "import os, sys, time; open(sys.argv[1], 'w').write(str(os.getpid())); time.sleep(600)"
+bench.worker_command = lambda argv: [sys.executable, '-c', child, marker]
+sys.exit(bench.supervise(['--gpus', '1'], attempt_timeout=300.0, ladder=[('only', {})], bonus_p2p=False))
+"""
+
+
+def test_a_terminated_supervisor_takes_its_worker_with_it(tmp_path):
+    """The worker of a rung lives in a session of its own, so nobody else reaps it: SIGTERM to the supervisor (the launcher
+    tearing the remaining ranks down, self_launch killing an overrun) must end the worker before the supervisor exits —
+    an orphaned rank would keep its GPU busy, inside an RCCL collective for minutes."""
+    import os
+    import signal
+    import time
+    bench = _bench()
+    marker = tmp_path / "worker.pid"
+    env = {**os.environ, "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+           "MASTER_PORT": str(bench._free_port())}
+    sup = subprocess.Popen([sys.executable, "-c", SIGNALLED_SUPERVISOR, str(ROOT / "bench.py"), str(marker)], env=env)
+    try:
+        deadline = time.monotonic() + 120
+        while not (marker.exists() and marker.read_text().strip()) and time.monotonic() < deadline:
+            assert sup.poll() is None, "the supervisor ended before its worker started"
+            time.sleep(0.2)
+        worker = int(marker.read_text())
+        os.kill(worker, 0)                                               # alive
+        sup.send_signal(signal.SIGTERM)
+        assert sup.wait(timeout=60) == 128 + signal.SIGTERM
+        for _ in range(100):                                             # ... and the worker is gone with it
+            try:
+                os.kill(worker, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.1)
+        else:
+            os.kill(worker, signal.SIGKILL)
+            raise AssertionError("the worker outlived its supervisor")
+    finally:
+        if sup.poll() is None:
+            sup.kill()
+
+
+def test_a_rank_over_the_peer_to_peer_transport_never_touches_the_nccl_backend(monkeypatch):
+    """The ladder's last rung is what is left when RCCL itself fails: such a rank joins torch.distributed over gloo and
+    keeps the small tensors of its collectives on the host — as the rehearsal and the best-effort rerun do."""
+    import torch
+    bench = _bench()
+    for env_name in ("PI_MI355_TRANSPORT", "PI_BENCH_SHARE_GPU"):
+        monkeypatch.delenv(env_name, raising=False)
+    assert not bench.over_p2p() and bench._collective_device(torch.device("cuda", 0)).type == "cuda"
+    monkeypatch.setenv("PI_MI355_TRANSPORT", "p2p")
+    assert bench.over_p2p() and bench._collective_device(torch.device("cuda", 0)).type == "cpu"
+    # every rung of the ladder that runs over the peer-to-peer transport says so in its environment (what over_p2p reads)
+    assert [m for m, e in bench.LADDER if e.get("PI_MI355_TRANSPORT") == "p2p"] == ["halo+overlap over p2p"]
+    assert bench.BONUS_P2P["PI_MI355_TRANSPORT"] == "p2p"
+    src = (ROOT / "bench.py").read_text()
+    assert src.count('init_process_group("nccl"') == 1 and 'if over_p2p():\n            dist.init_process_group("gloo")' in src

@@ -2,9 +2,10 @@
 tools/profile_counters.sh wrote under OUTDIR/<label>_<pass>/ into one JSON per label:
 per kernel, the mean over the last `PI_LAST` (default 20) dispatches of every counter, the mean
 kernel duration from the kernel trace of the same passes, and the derived figures the roofline
-needs (VALU instructions per wave, busy fraction, L2 hit rate, HBM-side bytes with the gfx950
-FETCH_SIZE correction of MI355X_MICROARCH.md section HBM: x2 for the streaming reads, calibrated
-by the identity-dynamics pass when present).
+needs (VALU instructions per wave, busy fraction, L2 hit rate, HBM-side bytes).  FETCH_SIZE_bytes / WRITE_SIZE_bytes are
+stored AS COUNTED; the consumer (bench.py) applies the calibrated correction — x 2.0 on FETCH_SIZE, measured on the sweeps'
+own load shapes and on the product's sweep with identity dynamics (tools/fetch_calibration.sh, profiles/r05/
+fetch_calibration.txt), x 1.0 on WRITE_SIZE; `hbm_bytes_corrected` is recorded beside them with the factor used.
 """
 import collections, csv, glob, json, os, subprocess, sys
 
@@ -13,6 +14,22 @@ labels = sys.argv[2:]
 LAST = int(os.environ.get("PI_LAST", "20"))
 ENV = os.environ.get("PI_ENV", "double_pendulum_swingup")
 BINS = int(os.environ.get("PI_BINS", "80"))
+
+
+def fetch_factor():
+    """The measured FETCH_SIZE correction: mean over the load shapes the sweeps use of the latest committed
+    profiles/r*/fetch_calibration.json (tools/fetch_calibration.sh); 2.0 — the value every such measurement gave — without one."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "fetch_calibration.json")))
+    if not files:
+        return 2.0
+    micro = json.load(open(files[-1])).get("micro", {})
+    shapes = [micro[k]["fetch_factor"] for k in ("cal_overlap8", "cal_stream4_nt", "cal_stream1_nt", "cal_gather8_line")
+              if "fetch_factor" in micro.get(k, {})]
+    return round(sum(shapes) / len(shapes), 2) if shapes else 2.0
+
+
+FETCH_FACTOR = fetch_factor()
 
 
 def head_hash():
@@ -143,6 +160,9 @@ for label in labels:
             e["FETCH_SIZE_bytes"] = c["FETCH_SIZE"] * 1024.0
         if "WRITE_SIZE" in c:
             e["WRITE_SIZE_bytes"] = c["WRITE_SIZE"] * 1024.0
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            e["fetch_correction_factor"] = FETCH_FACTOR
+            e["hbm_bytes_corrected"] = FETCH_FACTOR * e["FETCH_SIZE_bytes"] + e["WRITE_SIZE_bytes"]
         res["kernels"][k] = e
     if label == "cal":
         cal = res
