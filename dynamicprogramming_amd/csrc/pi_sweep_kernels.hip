@@ -879,6 +879,216 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 }
 #endif
 
+// ---- dataflow evaluation for launch-bound grids (too big for one CU's LDS, too small to fill the chip) -------
+// A grid of a few ten thousand states (BASELINE config C2: pendulum 200 x 200) sweeps in ~2 us of kernel time, and a
+// policy evaluation is thousands of DEPENDENT sweeps: as launches, each sweep pays a kernel boundary (~1.45 us) plus a
+// launch's fill and drain — 3.9 us per sweep in 25-node graphs (profiles/r04/bench_c2.json), whatever the kernel does.
+// This kernel runs the reference's whole policy_evaluation loop (:300-336) in ONE launch across many workgroups with NO
+// grid barrier between sweeps.  As in pi_eval_resident_kernel a state's successor cell, fractional offsets and reward are
+// computed once and stay in registers (the policy is fixed).  The iterates travel between workgroups as data-tagged
+// granules: version j of V (the iterate after sweep j) lives in ring[j % 3] as one naturally aligned 8-byte word per
+// state, {tag = j + 1, value bits}, written by ONE agent-scope atomic store and read by agent-scope atomic loads
+// (global_store/load_dwordx2 sc1: per-location coherence of an 8-byte atomic object is all the hand-off relies on —
+// no flag, no fence).  A wave computes sweep j for its states as soon as the 2^D corner granules of each carry tag j:
+// the critical path of a sweep is ONE store -> load hop (~1 us, MI355X_MICROARCH.md row handoff-1to1), not a barrier.
+// Buffer reuse needs flow control: version j overwrites version j - 3, which the workgroups computing sweep j - 2 read,
+// so a workgroup stores version j only once EVERY workgroup has completed sweep j - 2 — told by per-workgroup progress
+// words (a workgroup's lane 0 stores "sweeps completed" after all its waves' stores have drained and a workgroup
+// barrier).  That condition was reached a whole sweep earlier in the common case, so it costs a poll that succeeds at
+// once, and it bounds the skew between workgroups to two sweeps.  The slowest workgroup can always proceed (its inputs
+// cannot have been overwritten, its own store is always allowed), so the scheme cannot deadlock while every workgroup
+// is resident — the host launches at most as many as the occupancy query admits.  The residual is looked at on sweeps 0,
+// check_interval, 2 check_interval, ... and the last one exactly as the host loop does: on those sweeps every
+// workgroup folds its maximum into checks[look] (atomic max of the bit pattern) before it reports progress, waits for
+// ALL progress words (the one real barrier, every 25 sweeps) and reads the same maximum, so all stop together.
+// EVERY wait is bounded (timeout_ticks of the 100 MHz wall clock): a wave that gives up raises the status word (kept
+// behind the progress words, so every poll sees it), the workgroups leave the loop together through an LDS flag behind
+// their barrier, and *sweeps_out = -1 tells the host, which fails loudly.  Arithmetic identical to
+// pi_eval_sweep_kernel's, hence the same bits, residuals and sweep counts.
+#ifndef PI_FLOW
+#define PI_FLOW 0
+#endif
+#if PI_FLOW
+#ifndef PI_FLOW_BLOCK
+#define PI_FLOW_BLOCK 256
+#endif
+#define PI_FLOW_RING 3
+typedef unsigned long long PiGranule;                    // tag (high half) | float32 bits (low half)
+__device__ __forceinline__ unsigned int pi_flow_load32(const unsigned int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Spin until every one of the W progress words has reached `need`; false on a time-out or when another wave has raised
+// the status word progress[W].  Wave-uniform result.
+__device__ __forceinline__ bool pi_flow_wait(const unsigned int* __restrict__ progress, unsigned int W, unsigned int need,
+                                             unsigned long long ticks) {
+    const unsigned int lane = threadIdx.x & 63u;
+    unsigned long long t0 = 0ull;
+    bool timing = false;
+    while (true) {
+        bool ok = true, failed = false;
+        for (unsigned int i = lane; i <= W; i += 64u) {
+            const unsigned int v = pi_flow_load32(progress + i);
+            if (i < W) ok = ok && v >= need;
+            else failed = v != 0u;
+        }
+        if (__any(failed)) return false;
+        if (__all(ok)) return true;
+        if (!timing) { t0 = wall_clock64(); timing = true; }
+        else if (wall_clock64() - t0 > ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
+pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                    const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
+                    int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
+                    PiGranule* __restrict__ ring, unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
+                    unsigned long long timeout_ticks) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ float lds_red[PI_FLOW_BLOCK / 64];
+    __shared__ unsigned int lds_dead, lds_verdict;
+    constexpr unsigned int N = (unsigned int)PI_GRID.n;
+    const unsigned int W = gridDim.x;
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    const unsigned int s = blockIdx.x * PI_FLOW_BLOCK + tid;
+    if (tid == 0u) { lds_dead = 0u; lds_verdict = 0u; }
+    pi_stage_table<PI_FLOW_BLOCK>(tab, lds_tab);
+    __syncthreads();
+
+    // per state, once: 0 = no state (tail), 1 = terminal (keeps its value), 2 = done successor (no bootstrap), 3 = interpolates
+    unsigned int kind = 0u, base = 0u;
+    float fr[PI_D], reward = 0.0f, v_cur = 0.0f;
+#pragma unroll
+    for (int d = 0; d < PI_D; ++d) fr[d] = 0.0f;
+    if (s < N) {
+        v_cur = Va[s];
+        kind = 1u;
+        if (term == nullptr || !term[s]) {
+            float x[PI_D], ns[PI_D];
+            pi_state_coords(s, lds_tab, x);
+            bool done;
+            pi_dynamics(x, lds_tab[PI_TAB_ACT + pi_checked_action(policy[s], s)], ns, &reward, &done);
+            kind = 2u;
+            if (!done) {
+                pi_locate(ns, base, fr);
+                kind = 3u;
+            }
+        }
+    }
+
+    bool dead = false;                                     // wave-uniform: this wave has given up waiting
+    int done_sweeps = 0;
+    float residual = 0.0f;
+    for (int j = 0; j < n_sweeps; ++j) {
+        float w[PI_C], v[PI_C];
+        pi_corner_weights(fr, w);
+#pragma unroll
+        for (int c = 0; c < PI_C; ++c) v[c] = 0.0f;
+        if (j == 0) {                                      // the caller's V: written before this launch, plain loads
+            if (kind == 3u) {
+#pragma unroll
+                for (int c = 0; c < PI_C; ++c) v[c] = Va[base + (unsigned int)pi_corner_offset(c)];
+            }
+        } else if (!dead) {
+            const PiGranule* src = ring + (size_t)((j - 1) % PI_FLOW_RING) * N;
+            const unsigned int want = (unsigned int)j;    // tag of version j - 1
+            unsigned long long t0 = 0ull;
+            bool timing = false;
+            while (true) {
+                bool ok = true;
+                if (kind == 3u) {
+                    PiGranule g[PI_C];
+#pragma unroll
+                    for (int c = 0; c < PI_C; ++c)
+                        g[c] = __hip_atomic_load(src + base + (unsigned int)pi_corner_offset(c), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int c = 0; c < PI_C; ++c) {
+                        ok = ok && (unsigned int)(g[c] >> 32) == want;
+                        v[c] = __uint_as_float((unsigned int)g[c]);
+                    }
+                }
+                if (__all(ok)) break;
+                if (!timing) { t0 = wall_clock64(); timing = true; }
+                else if (wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
+                if (pi_flow_load32(progress + W) != 0u) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        float e = 0.0f;
+#pragma unroll
+        for (int c = 0; c < PI_C; ++c) e = fmaf(w[pi_corner_mask(c)], v[c], e);
+        const float q = reward + gamma * (kind == 3u ? e : 0.0f);
+        const float nv = kind >= 2u ? q : v_cur;
+        const bool last = j == n_sweeps - 1;
+        const bool look = last || j % check_interval == 0;
+        const float dlt = fabsf(nv - v_cur);               // 0 for lanes without a state
+        v_cur = nv;
+        // version j may replace version j - 3 once every workgroup has completed sweep j - 2
+        if (j >= 2 && !dead) dead = !pi_flow_wait(progress, W, (unsigned int)(j - 1), timeout_ticks);
+        if (!dead && kind != 0u)
+            __hip_atomic_store(ring + (size_t)(j % PI_FLOW_RING) * N + s,
+                               ((PiGranule)(unsigned int)(j + 1) << 32) | (PiGranule)__float_as_uint(nv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (look) {
+            const float wmax = pi_wave_max(dlt);
+            if (lane == 0u) lds_red[tid >> 6] = wmax;
+        }
+        if (dead && lane == 0u) {
+            lds_dead = 1u;
+            __hip_atomic_store(progress + W, 1u + (unsigned int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's granules have left before the workgroup reports
+        __syncthreads();
+        if (lds_dead != 0u) { dead = true; break; }        // workgroup-uniform: every wave reads the flag behind the barrier
+        done_sweeps = j + 1;
+        const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
+        if (tid == 0u) {
+            if (look) {
+                float m = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < PI_FLOW_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
+                if (m > 0.0f) (void)atomicMax(checks + slot, __float_as_uint(m));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the maximum is in before the progress word says so
+            }
+            __hip_atomic_store(progress + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (look) {
+            // the one real barrier: every workgroup has folded its maximum in; wave 0 waits, the others learn through LDS
+            if (tid < 64u) {
+                const bool ok = pi_flow_wait(progress, W, (unsigned int)(j + 1), timeout_ticks);
+                if (lane == 0u) {
+                    lds_verdict = ok ? pi_flow_load32(checks + slot) : 0xFFFFFFFFu;
+                    if (!ok) __hip_atomic_store(progress + W, 0x80000000u + (unsigned int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            const unsigned int bits = lds_verdict;
+            if (bits == 0xFFFFFFFFu) { dead = true; break; }
+            residual = __uint_as_float(bits);
+            if (blockIdx.x == 0u && tid == 0u) residual_log[slot] = residual;
+            if ((double)residual < theta) break;
+            __syncthreads();                               // lds_verdict / lds_red are reused at the next look
+        }
+    }
+    if (dead) {
+        if (blockIdx.x == 0u && tid == 0u) *sweeps_out = -1;
+        return;
+    }
+    if (kind != 0u) Va[s] = v_cur;
+    if (blockIdx.x == 0u && tid == 0u) {
+        *sweeps_out = done_sweeps;
+        if (delta_out != nullptr) *delta_out = residual;
+    }
+}
+// Launched right behind pi_eval_flow_kernel: a workgroup may have given up inside the LAST barrier while the others went
+// through it, so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
+extern "C" __global__ void __launch_bounds__(64)
+pi_flow_finish_kernel(const unsigned int* __restrict__ progress, unsigned int W, int* __restrict__ sweeps_out) {
+    if (threadIdx.x == 0u && pi_flow_load32(progress + W) != 0u) *sweeps_out = -1;
+}
+#endif
+
 // ---- greedy policy improvement sweep -------------------------------------------
 // policy[s] = argmax_a [ r(s,a) + gamma * E[V](s'_a) ], first maximum wins; terminal
 // states keep their entry.  changed (nullable): slots counting the entries that changed.

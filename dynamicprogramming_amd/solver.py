@@ -115,9 +115,9 @@ class HipSweepBackend:
 
     @property
     def resident(self) -> bool:
-        """True when the grid is small enough for the library's LDS-resident kernel, which runs a
-        whole policy evaluation (all sweeps and residual checks) in one launch."""
-        return self.engine.info(13) > 0 and self.engine.info(14) == 1
+        """True when the library runs a whole policy evaluation (all sweeps and residual checks) of this grid in one
+        launch: the LDS-resident kernel for grids one CU holds, the dataflow kernel for launch-bound grids beyond."""
+        return (self.engine.info(13) > 0 or self.engine.info(19) > 0) and self.engine.info(14) == 1
 
     def policy_evaluation(self, V, policy, term, gamma, theta, max_sweeps, check_interval):
         """The whole evaluation loop on the device (pi_policy_evaluation): returns (sweeps done,
@@ -131,6 +131,10 @@ class HipSweepBackend:
                                       self._stream())
         host = out.cpu()
         done = int(host[looks:].view(torch.int32).item())
+        if done < 0:
+            raise RuntimeError("pi_policy_evaluation: a workgroup of the one-launch evaluation kernel gave up waiting for "
+                               "its peers (PI_MI355_FLOW_TIMEOUT); V is undefined — PI_MI355_FLOW=0 selects the "
+                               "sweep-by-sweep path")
         n_looks = (done - 1) // check_interval + 1 + (1 if (done - 1) % check_interval else 0)
         return done, host[:n_looks].numpy()
 

@@ -146,13 +146,18 @@ int pi_eval_end(pi_handle* h);
 
 /*
  * The whole policy_evaluation loop (:300-336) in ONE launch, for grids the LDS-resident kernel
- * holds (pi_info 13 > 0; fails otherwise): up to max_sweeps Jacobi sweeps of the whole grid under
+ * holds (pi_info 13 > 0: up to 12 288 states in 2-D, 4 096 in 4-D, 1 024 in 6-D) and, beyond those, for
+ * launch-bound grids of up to 2^17 states in 2-D / 4-D (pi_info 19 > 0 = workgroups of the dataflow kernel:
+ * the iterates travel between workgroups as tagged 8-byte granules, no grid barrier between sweeps; BASELINE
+ * config C2, pendulum 200 x 200, is one); fails on every other grid: up to max_sweeps Jacobi sweeps of the whole grid under
  * `policy`, the residual looked at on sweeps 0, check_interval, 2 check_interval, ... (the
  * reference's SYNC_INTERVAL = 25) and on the last one, stopping at the first residual below theta.
  * V is updated in place (the newest iterate); *d_sweeps receives the number of sweeps done,
  * *d_delta (nullable) the last residual looked at, d_residual_log[k] every residual looked at
  * (k-th look; at least max_sweeps / check_interval + 2 floats).  Same arithmetic, same sweep
  * count and same V as the same loop driven from the host through pi_eval_sweeps.
+ * Dataflow kernel only: every device-side wait is bounded (PI_MI355_FLOW_TIMEOUT seconds, default 2); when a
+ * workgroup gives up, *d_sweeps = -1 and V is undefined — the caller must treat that as an error.
  */
 int pi_policy_evaluation(pi_handle* h, float* V, const int32_t* policy, const uint8_t* term, float gamma,
                          double theta, int max_sweeps, int check_interval, int32_t* d_sweeps, float* d_delta,

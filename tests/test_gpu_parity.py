@@ -483,12 +483,18 @@ def test_small_grids_run_whole_batches_in_lds(name, shape, cuda_device):
     eng.close()
 
 
-@pytest.mark.parametrize("name,bins,max_eval", [("pendulum", 50, 5000), ("mountain_car", 64, 300),
-                                                ("cartpole", 8, 5000), ("double_pendulum_swingup", 8, 777)])
-def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, cuda_device, monkeypatch):
+@pytest.mark.parametrize("name,bins,max_eval,kernel", [
+    ("pendulum", 50, 5000, "lds"), ("mountain_car", 64, 300, "lds"), ("cartpole", 8, 5000, "lds"),
+    ("double_pendulum_swingup", 8, 777, "lds"),
+    # launch-bound grids beyond one CU's LDS: the dataflow kernel (BASELINE config C2 is the first; 113 x 113 has a ragged
+    # last workgroup; cartpole 15^4 has terminal states; the double pendulum wraps two angles)
+    ("pendulum", 200, 5000, "flow"), ("mountain_car", 113, 700, "flow"), ("cartpole", 15, 1200, "flow"),
+    ("double_pendulum_swingup", 15, 777, "flow")])
+def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel, cuda_device, monkeypatch):
     """pi_policy_evaluation runs the reference's evaluation loop (sweeps, the residual looked at on
-    sweeps 0, 25, 50, ... and the last, stop below theta) in one launch with V in LDS: same number
-    of sweeps, same residual, same V — and the same full run() — as the host-driven loop."""
+    sweeps 0, 25, 50, ... and the last, stop below theta) in ONE launch — with V in one CU's LDS on grids that fit it,
+    as tagged granules flowing between workgroups (pi_eval_flow_kernel) on launch-bound grids beyond: same number
+    of sweeps, same residuals, same V — and the same full run() — as the host-driven loop."""
     torch = _torch()
     cfg = dict(envs.ENVS[name].CONFIG, max_eval_iter=max_eval, max_pi_iter=6)
     solvers = {}
@@ -498,6 +504,8 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, cuda_d
         assert s._backend.resident == (resident == "1")
         solvers[resident] = s
     a, b = solvers["1"], solvers["0"]
+    assert (a._backend.engine.info(13) > 0) == (kernel == "lds") and (a._backend.engine.info(19) > 0) == (kernel == "flow")
+    assert b._backend.engine.info(13) == 0 and b._backend.engine.info(19) == 0
     # one evaluation from the same start (zero V, zero policy; cartpole has terminal states)
     da, db = a.policy_evaluation(), b.policy_evaluation()
     assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"]
