@@ -883,28 +883,39 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 // A grid of a few ten thousand states (BASELINE config C2: pendulum 200 x 200) sweeps in ~2 us of kernel time, and a
 // policy evaluation is thousands of DEPENDENT sweeps: as launches, each sweep pays a kernel boundary (~1.45 us) plus a
 // launch's fill and drain — 3.9 us per sweep in 25-node graphs (profiles/r04/bench_c2.json), whatever the kernel does.
-// This kernel runs the reference's whole policy_evaluation loop (:300-336) in ONE launch across many workgroups with NO
-// grid barrier between sweeps.  As in pi_eval_resident_kernel a state's successor cell, fractional offsets and reward are
-// computed once and stay in registers (the policy is fixed).  The iterates travel between workgroups as data-tagged
-// granules: version j of V (the iterate after sweep j) lives in ring[j % 3] as one naturally aligned 8-byte word per
-// state, {tag = j + 1, value bits}, written by ONE agent-scope atomic store and read by agent-scope atomic loads
-// (global_store/load_dwordx2 sc1: per-location coherence of an 8-byte atomic object is all the hand-off relies on —
-// no flag, no fence).  A wave computes sweep j for its states as soon as the 2^D corner granules of each carry tag j:
-// the critical path of a sweep is ONE store -> load hop (~1 us, MI355X_MICROARCH.md row handoff-1to1), not a barrier.
-// Buffer reuse needs flow control: version j overwrites version j - 3, which the workgroups computing sweep j - 2 read,
-// so a workgroup stores version j only once EVERY workgroup has completed sweep j - 2 — told by per-workgroup progress
-// words (a workgroup's lane 0 stores "sweeps completed" after all its waves' stores have drained and a workgroup
-// barrier).  That condition was reached a whole sweep earlier in the common case, so it costs a poll that succeeds at
-// once, and it bounds the skew between workgroups to two sweeps.  The slowest workgroup can always proceed (its inputs
-// cannot have been overwritten, its own store is always allowed), so the scheme cannot deadlock while every workgroup
-// is resident — the host launches at most as many as the occupancy query admits.  The residual is looked at on sweeps 0,
-// check_interval, 2 check_interval, ... and the last one exactly as the host loop does: on those sweeps every
-// workgroup folds its maximum into checks[look] (atomic max of the bit pattern) before it reports progress, waits for
-// ALL progress words (the one real barrier, every 25 sweeps) and reads the same maximum, so all stop together.
-// EVERY wait is bounded (timeout_ticks of the 100 MHz wall clock): a wave that gives up raises the status word (kept
-// behind the progress words, so every poll sees it), the workgroups leave the loop together through an LDS flag behind
-// their barrier, and *sweeps_out = -1 tells the host, which fails loudly.  Arithmetic identical to
-// pi_eval_sweep_kernel's, hence the same bits, residuals and sweep counts.
+// These kernels run the reference's whole policy_evaluation loop (:300-336) in ONE launch across many workgroups with
+// NO barrier of any kind between sweeps.  As in pi_eval_resident_kernel a state's successor cell, fractional offsets
+// and reward are computed once and stay in registers (the policy is fixed).  The iterates travel between waves as
+// data-tagged granules: version j of V (the iterate after sweep j) lives in ring[j % 16] as one naturally aligned 8-byte
+// word per state, {tag = j + 1, value bits}, written by ONE 8-byte store and read by 8-byte loads that bypass the
+// reader's L1.  A wave computes sweep j for its 64 states as soon as the 2^D corner granules of each carry tag j: the
+// critical path of a sweep is ONE store -> load hop, nothing else.
+//   * Buffer reuse: version j overwrites version j - 16, which sweep j - 15 reads, so it may be stored only once EVERY
+//     workgroup has completed sweep j - 15.  Workgroups publish "sweeps completed" in per-workgroup progress words; a
+//     wave remembers the minimum it last saw and reads the words again only when that no longer covers its store —
+//     every ~13 sweeps, in the same round trip as its corner granules.  The rule bounds the skew between waves to 15
+//     sweeps, and the slowest wave can always proceed (its inputs cannot have been overwritten, its own store is always
+//     allowed): no deadlock while every participating workgroup is resident.
+//   * Completion of sweep j - 1 is reported when the poll of sweep j has come back — by then the wave's store has
+//     drained, for free — through a counter in LDS: the last of a workgroup's waves to report writes the progress word.
+//   * The residual is looked at on sweeps 0, check_interval, 2 check_interval, ... and the last one exactly as the host
+//     loop does: on those sweeps a wave drains and reports at once, the workgroup's last reporter folds the
+//     workgroup's maximum into checks[look] (atomic max of the bit pattern) BEFORE it writes the progress word, wave 0
+//     of every workgroup waits for ALL progress words (the one real barrier, every 25 sweeps), reads the maximum and
+//     hands it to the workgroup's other waves through LDS: all stop together.
+//   * EVERY wait is bounded (timeout_ticks of the 100 MHz wall clock): a wave that gives up raises the status word
+//     (behind the progress words) and leaves; pi_flow_finish_kernel turns a raised status word into *sweeps_out = -1.
+// Two forms of the same loop (template parameter LOCAL):
+//   pi_eval_flow_kernel        the hand-off is an agent-scope atomic store / load pair (global_store/load_dwordx2 sc1):
+//                              correct wherever the workgroups run; a hop is a round trip through the fabric.
+//   pi_eval_flow_local_kernel  XCD-aware: all participating workgroups run on ONE XCD and hand off through that XCD's
+//                              L2 (plain 8-byte stores, sc1 loads), a tenth of the fabric's latency.  HIP promises
+//                              nothing about placement, so nothing is assumed: the host launches spare workgroups, each
+//                              reads its XCC id from the hardware register, the first `n_wgs` that find themselves on
+//                              XCD 0 take a ticket and participate, all others leave at once.  Too few on XCD 0 means
+//                              a bounded wait runs out, *sweeps_out = -1, and the host runs the evaluation again in the
+//                              placement-independent form (V is only written at the very end, so nothing is lost).
+// Arithmetic identical to pi_eval_sweep_kernel's, hence the same bits, residuals and sweep counts.
 #ifndef PI_FLOW
 #define PI_FLOW 0
 #endif
@@ -912,48 +923,95 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 #ifndef PI_FLOW_BLOCK
 #define PI_FLOW_BLOCK 256
 #endif
-#define PI_FLOW_RING 3
+#define PI_FLOW_RING 16
+#define PI_FLOW_WAVES (PI_FLOW_BLOCK / 64)
+#define PI_FLOW_DEAD 0xFFFFFFFFu
 typedef unsigned long long PiGranule;                    // tag (high half) | float32 bits (low half)
 __device__ __forceinline__ unsigned int pi_flow_load32(const unsigned int* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // sc1: never served by this CU's L1
 }
-// Spin until every one of the W progress words has reached `need`; false on a time-out or when another wave has raised
-// the status word progress[W].  Wave-uniform result.
-__device__ __forceinline__ bool pi_flow_wait(const unsigned int* __restrict__ progress, unsigned int W, unsigned int need,
-                                             unsigned long long ticks) {
-    const unsigned int lane = threadIdx.x & 63u;
-    unsigned long long t0 = 0ull;
-    bool timing = false;
-    while (true) {
-        bool ok = true, failed = false;
-        for (unsigned int i = lane; i <= W; i += 64u) {
-            const unsigned int v = pi_flow_load32(progress + i);
-            if (i < W) ok = ok && v >= need;
-            else failed = v != 0u;
+template <bool LOCAL>
+__device__ __forceinline__ void pi_flow_store32(unsigned int* p, unsigned int v) {
+    if (LOCAL) *reinterpret_cast<volatile unsigned int*>(p) = v;                   // stays in the XCD's L2
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void pi_flow_store64(PiGranule* p, PiGranule v) {
+    if (LOCAL) *reinterpret_cast<volatile PiGranule*>(p) = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One wave reports that it has completed sweep k (its granules of version k have left: the caller has waited for its
+// vector-memory counter).  The last wave of the workgroup to do so publishes the workgroup's progress — after folding
+// the workgroup's residual maximum into checks[slot] when sweep k is one the residual is looked at.
+template <bool LOCAL>
+__device__ __forceinline__ void pi_flow_report(int k, bool look, int slot, float wave_max, unsigned int wg,
+                                               unsigned int* lds_count, unsigned int* lds_max,
+                                               unsigned int* __restrict__ progress, unsigned int* __restrict__ checks) {
+    if ((threadIdx.x & 63u) != 0u) return;
+    if (look && wave_max > 0.0f) (void)atomicMax(lds_max + (slot & 1), __float_as_uint(wave_max));
+    const unsigned int before = atomicAdd(lds_count + (k & 31), 1u);
+    if (before != PI_FLOW_WAVES - 1u) return;
+    lds_count[k & 31] = 0u;                                // next used 32 sweeps on; the skew is at most 15
+    if (look) {
+        const unsigned int m = atomicExch(lds_max + (slot & 1), 0u);
+        if (m != 0u) {
+            const unsigned int was = atomicMax(checks + slot, m);          // returning: complete before the word below
+            asm volatile("" ::"v"(was));
         }
-        if (__any(failed)) return false;
-        if (__all(ok)) return true;
-        if (!timing) { t0 = wall_clock64(); timing = true; }
-        else if (wall_clock64() - t0 > ticks) return false;
-        __builtin_amdgcn_s_sleep(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    pi_flow_store32<LOCAL>(progress + wg, (unsigned int)(k + 1));
 }
-extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
-pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                    const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
-                    int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
-                    PiGranule* __restrict__ ring, unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
-                    unsigned long long timeout_ticks) {
+// All W progress words and the status word behind them, one load per 64 words: the smallest progress, or PI_FLOW_DEAD
+// when the status word is raised.  Wave-uniform.
+__device__ __forceinline__ unsigned int pi_flow_min_progress(const unsigned int* __restrict__ progress, unsigned int W) {
+    const unsigned int lane = threadIdx.x & 63u;
+    unsigned int m = 0x7FFFFFFFu;
+    bool failed = false;
+    for (unsigned int i = lane; i <= W; i += 64u) {
+        const unsigned int p = pi_flow_load32(progress + i);
+        if (i < W) m = min(m, p);
+        else failed = p != 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned int)__shfl_xor((int)m, o, 64));
+    return __any(failed) ? PI_FLOW_DEAD : m;
+}
+template <bool LOCAL>
+__device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* __restrict__ policy,
+                                             const unsigned char* __restrict__ term, const float* __restrict__ tab,
+                                             float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
+                                             int check_interval, int* __restrict__ sweeps_out,
+                                             float* __restrict__ residual_log, PiGranule* __restrict__ ring,
+                                             unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
+                                             unsigned long long timeout_ticks, unsigned int W,
+                                             unsigned int* __restrict__ tickets) {
     __shared__ float lds_tab[PI_GRID.tab_len];
-    __shared__ float lds_red[PI_FLOW_BLOCK / 64];
-    __shared__ unsigned int lds_dead, lds_verdict;
+    __shared__ unsigned int lds_count[32], lds_max[2], lds_wg, lds_seq, lds_bits;
     constexpr unsigned int N = (unsigned int)PI_GRID.n;
-    const unsigned int W = gridDim.x;
     const unsigned int tid = threadIdx.x, lane = tid & 63u;
-    const unsigned int s = blockIdx.x * PI_FLOW_BLOCK + tid;
-    if (tid == 0u) { lds_dead = 0u; lds_verdict = 0u; }
+    if (tid < 32u) lds_count[tid] = 0u;
+    if (tid < 2u) lds_max[tid] = 0u;
+    if (tid == 0u) {
+        lds_seq = 0u;
+        lds_bits = 0u;
+        unsigned int wg = blockIdx.x;
+        if (LOCAL) {                                       // participants: the first W workgroups that run on XCD 0
+            unsigned int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            wg = PI_FLOW_DEAD;
+            if ((xcc & 15u) == 0u) {
+                const unsigned int t = atomicAdd(tickets, 1u);
+                if (t < W) wg = t;
+            }
+        }
+        lds_wg = wg;
+    }
     pi_stage_table<PI_FLOW_BLOCK>(tab, lds_tab);
-    __syncthreads();
+    __syncthreads();                                       // the only workgroup barrier of the kernel
+    const unsigned int wg = lds_wg;
+    if (wg == PI_FLOW_DEAD) return;                        // a spare workgroup, or one on another XCD
+    const unsigned int s = wg * PI_FLOW_BLOCK + tid;
 
     // per state, once: 0 = no state (tail), 1 = terminal (keeps its value), 2 = done successor (no bootstrap), 3 = interpolates
     unsigned int kind = 0u, base = 0u;
@@ -976,10 +1034,12 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
         }
     }
 
-    bool dead = false;                                     // wave-uniform: this wave has given up waiting
-    int done_sweeps = 0;
+    bool dead = false;                                     // wave-uniform
+    int done_sweeps = 0, reported = 0;                     // sweeps this wave has computed / reported as complete
+    unsigned int known = 0u;                               // every workgroup has completed at least this many sweeps
+    unsigned int looks = 0u;                               // residual looks so far (sequence number of the LDS hand-over)
     float residual = 0.0f;
-    for (int j = 0; j < n_sweeps; ++j) {
+    for (int j = 0; j < n_sweeps && !dead; ++j) {
         float w[PI_C], v[PI_C];
         pi_corner_weights(fr, w);
 #pragma unroll
@@ -989,30 +1049,46 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 #pragma unroll
                 for (int c = 0; c < PI_C; ++c) v[c] = Va[base + (unsigned int)pi_corner_offset(c)];
             }
-        } else if (!dead) {
+        } else {
+            // one poll = one round trip: the corner granules of version j - 1 and, when the remembered minimum no longer
+            // covers this sweep's store, every progress word with the status word
             const PiGranule* src = ring + (size_t)((j - 1) % PI_FLOW_RING) * N;
             const unsigned int want = (unsigned int)j;    // tag of version j - 1
+            const unsigned int need = j + 2 > PI_FLOW_RING ? (unsigned int)(j + 2 - PI_FLOW_RING) : 0u;
             unsigned long long t0 = 0ull;
-            bool timing = false;
+            unsigned int spins = 0u;
             while (true) {
                 bool ok = true;
+                PiGranule g[PI_C];
                 if (kind == 3u) {
-                    PiGranule g[PI_C];
 #pragma unroll
                     for (int c = 0; c < PI_C; ++c)
                         g[c] = __hip_atomic_load(src + base + (unsigned int)pi_corner_offset(c), __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (known < need || (spins & 255u) == 255u) {          // also: look at the status word now and then
+                    const unsigned int m = pi_flow_min_progress(progress, W);
+                    if (m == PI_FLOW_DEAD) { dead = true; break; }
+                    known = m;
+                }
+                if (kind == 3u) {
 #pragma unroll
                     for (int c = 0; c < PI_C; ++c) {
                         ok = ok && (unsigned int)(g[c] >> 32) == want;
                         v[c] = __uint_as_float((unsigned int)g[c]);
                     }
                 }
-                if (__all(ok)) break;
-                if (!timing) { t0 = wall_clock64(); timing = true; }
-                else if (wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
-                if (pi_flow_load32(progress + W) != 0u) { dead = true; break; }
+                if (__all(ok) && known >= need) break;
+                if (spins == 0u) t0 = wall_clock64();
+                else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
+                ++spins;
                 __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+            if (reported < j) {                            // sweep j - 1: its store went out before this poll came back
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pi_flow_report<LOCAL>(j - 1, false, 0, 0.0f, wg, lds_count, lds_max, progress, checks);
+                reported = j;
             }
         }
         float e = 0.0f;
@@ -1024,65 +1100,90 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
         const bool look = last || j % check_interval == 0;
         const float dlt = fabsf(nv - v_cur);               // 0 for lanes without a state
         v_cur = nv;
-        // version j may replace version j - 3 once every workgroup has completed sweep j - 2
-        if (j >= 2 && !dead) dead = !pi_flow_wait(progress, W, (unsigned int)(j - 1), timeout_ticks);
-        if (!dead && kind != 0u)
-            __hip_atomic_store(ring + (size_t)(j % PI_FLOW_RING) * N + s,
-                               ((PiGranule)(unsigned int)(j + 1) << 32) | (PiGranule)__float_as_uint(nv), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        if (look) {
-            const float wmax = pi_wave_max(dlt);
-            if (lane == 0u) lds_red[tid >> 6] = wmax;
-        }
-        if (dead && lane == 0u) {
-            lds_dead = 1u;
-            __hip_atomic_store(progress + W, 1u + (unsigned int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's granules have left before the workgroup reports
-        __syncthreads();
-        if (lds_dead != 0u) { dead = true; break; }        // workgroup-uniform: every wave reads the flag behind the barrier
+        if (kind != 0u)
+            pi_flow_store64<LOCAL>(ring + (size_t)(j % PI_FLOW_RING) * N + s,
+                                   ((PiGranule)(unsigned int)(j + 1) << 32) | (PiGranule)__float_as_uint(nv));
         done_sweeps = j + 1;
-        const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
-        if (tid == 0u) {
-            if (look) {
-                float m = 0.0f;
-#pragma unroll
-                for (int wv = 0; wv < PI_FLOW_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
-                if (m > 0.0f) (void)atomicMax(checks + slot, __float_as_uint(m));
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the maximum is in before the progress word says so
-            }
-            __hip_atomic_store(progress + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (look) {
-            // the one real barrier: every workgroup has folded its maximum in; wave 0 waits, the others learn through LDS
-            if (tid < 64u) {
-                const bool ok = pi_flow_wait(progress, W, (unsigned int)(j + 1), timeout_ticks);
-                if (lane == 0u) {
-                    lds_verdict = ok ? pi_flow_load32(checks + slot) : 0xFFFFFFFFu;
-                    if (!ok) __hip_atomic_store(progress + W, 0x80000000u + (unsigned int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // drain and report at once, then the one real barrier: every workgroup's maximum is in when its word says j + 1
+            const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
+            const float wave_max = pi_wave_max(dlt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pi_flow_report<LOCAL>(j, true, slot, wave_max, wg, lds_count, lds_max, progress, checks);
+            reported = j + 1;
+            ++looks;
+            unsigned long long t0 = 0ull;
+            unsigned int spins = 0u, bits = 0u;
+            if (tid < 64u) {                               // wave 0 waits for everyone and hands the verdict over in LDS
+                while (true) {
+                    const unsigned int m = pi_flow_min_progress(progress, W);
+                    if (m == PI_FLOW_DEAD) { dead = true; break; }
+                    known = m;
+                    if (m >= (unsigned int)(j + 1)) break;
+                    if (spins == 0u) t0 = wall_clock64();
+                    else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
+                    ++spins;
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                if (!dead) bits = pi_flow_load32(checks + slot);      // issued after every word was seen at j + 1
+                if (lane == 0u) {
+                    *reinterpret_cast<volatile unsigned int*>(&lds_bits) = bits;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the bits are in LDS before the number
+                    *reinterpret_cast<volatile unsigned int*>(&lds_seq) = dead ? PI_FLOW_DEAD : looks;
+                }
+            } else {
+                while (true) {
+                    const unsigned int seq = *reinterpret_cast<volatile unsigned int*>(&lds_seq);
+                    if (seq == PI_FLOW_DEAD) { dead = true; break; }
+                    if (seq == looks) break;
+                    if (spins == 0u) t0 = wall_clock64();
+                    else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks + timeout_ticks) { dead = true; break; }
+                    ++spins;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                bits = *reinterpret_cast<volatile unsigned int*>(&lds_bits);
+                known = max(known, (unsigned int)(j + 1));
             }
-            __syncthreads();
-            const unsigned int bits = lds_verdict;
-            if (bits == 0xFFFFFFFFu) { dead = true; break; }
+            if (dead) break;
             residual = __uint_as_float(bits);
-            if (blockIdx.x == 0u && tid == 0u) residual_log[slot] = residual;
+            if (wg == 0u && tid == 0u) residual_log[slot] = residual;
             if ((double)residual < theta) break;
-            __syncthreads();                               // lds_verdict / lds_red are reused at the next look
         }
     }
     if (dead) {
-        if (blockIdx.x == 0u && tid == 0u) *sweeps_out = -1;
+        if (lane == 0u) {
+            pi_flow_store32<false>(progress + W, 1u + (unsigned int)done_sweeps);
+            *reinterpret_cast<volatile unsigned int*>(&lds_seq) = PI_FLOW_DEAD;
+        }
         return;
     }
     if (kind != 0u) Va[s] = v_cur;
-    if (blockIdx.x == 0u && tid == 0u) {
+    if (wg == 0u && tid == 0u) {
         *sweeps_out = done_sweeps;
         if (delta_out != nullptr) *delta_out = residual;
     }
 }
-// Launched right behind pi_eval_flow_kernel: a workgroup may have given up inside the LAST barrier while the others went
-// through it, so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
+extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
+pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                    const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
+                    int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
+                    PiGranule* __restrict__ ring, unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
+                    unsigned long long timeout_ticks, unsigned int n_wgs, unsigned int* __restrict__ tickets) {
+    pi_flow_body<false>(Va, policy, term, tab, gamma, n_sweeps, delta_out, theta, check_interval, sweeps_out, residual_log, ring,
+                        progress, checks, timeout_ticks, n_wgs, tickets);
+}
+extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
+pi_eval_flow_local_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                          const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out,
+                          double theta, int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
+                          PiGranule* __restrict__ ring, unsigned int* __restrict__ progress,
+                          unsigned int* __restrict__ checks, unsigned long long timeout_ticks, unsigned int n_wgs,
+                          unsigned int* __restrict__ tickets) {
+    pi_flow_body<true>(Va, policy, term, tab, gamma, n_sweeps, delta_out, theta, check_interval, sweeps_out, residual_log, ring,
+                       progress, checks, timeout_ticks, n_wgs, tickets);
+}
+// Launched right behind a dataflow kernel: a wave may have given up while the others went through their last barrier,
+// so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
 extern "C" __global__ void __launch_bounds__(64)
 pi_flow_finish_kernel(const unsigned int* __restrict__ progress, unsigned int W, int* __restrict__ sweeps_out) {
     if (threadIdx.x == 0u && pi_flow_load32(progress + W) != 0u) *sweeps_out = -1;
