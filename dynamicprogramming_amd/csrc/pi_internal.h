@@ -131,13 +131,9 @@ struct pi_handle {
     // granule versions | progress words + status | check slots (owned; sized for flow_sweeps sweeps).
     bool flow = false;
     int flow_block = 256;
-    hipFunction_t f_flow = nullptr, f_flow_local = nullptr, f_flow_finish = nullptr;
+    hipFunction_t f_flow = nullptr, f_flow_finish = nullptr;
     void* d_flow = nullptr;
     int flow_sweeps = 0;
-    // XCD-local form (pi_eval_flow_local_kernel): all workgroups on one XCD, hand-off through its L2.  flow_local: still
-    // worth trying (the grid fits one XCD and no attempt has failed); flow_local_used / _failed count evaluations.
-    bool flow_local = false;
-    int64_t flow_local_used = 0, flow_local_failed = 0;
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     // pi_prepare_mask: the non-terminal states of the mask at live_term, ascending (device, owned); in use only

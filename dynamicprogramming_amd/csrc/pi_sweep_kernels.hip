@@ -905,16 +905,11 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 //     hands it to the workgroup's other waves through LDS: all stop together.
 //   * EVERY wait is bounded (timeout_ticks of the 100 MHz wall clock): a wave that gives up raises the status word
 //     (behind the progress words) and leaves; pi_flow_finish_kernel turns a raised status word into *sweeps_out = -1.
-// Two forms of the same loop (template parameter LOCAL):
-//   pi_eval_flow_kernel        the hand-off is an agent-scope atomic store / load pair (global_store/load_dwordx2 sc1):
-//                              correct wherever the workgroups run; a hop is a round trip through the fabric.
-//   pi_eval_flow_local_kernel  XCD-aware: all participating workgroups run on ONE XCD and hand off through that XCD's
-//                              L2 (plain 8-byte stores, sc1 loads), a tenth of the fabric's latency.  HIP promises
-//                              nothing about placement, so nothing is assumed: the host launches spare workgroups, each
-//                              reads its XCC id from the hardware register, the first `n_wgs` that find themselves on
-//                              XCD 0 take a ticket and participate, all others leave at once.  Too few on XCD 0 means
-//                              a bounded wait runs out, *sweeps_out = -1, and the host runs the evaluation again in the
-//                              placement-independent form (V is only written at the very end, so nothing is lost).
+// The hand-off is an agent-scope atomic store / load pair (global_store/load_dwordx2 sc1): per-location coherence of an
+// 8-byte atomic object is all it relies on — no flag, no fence, no dependence on where a workgroup runs; a hop is a round
+// trip through the fabric.  (An XCD-aware form — all workgroups on one XCD, verified at run time from the XCC id
+// register, hand-off through that XCD's L2 — was built and is 4x SLOWER at this size: one XCD's L2 cannot serve the
+// polling of 625 waves; profiles/r05/negative_results.txt (1).)
 // Arithmetic identical to pi_eval_sweep_kernel's, hence the same bits, residuals and sweep counts.
 #ifndef PI_FLOW
 #define PI_FLOW 0
@@ -924,26 +919,21 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
 #define PI_FLOW_BLOCK 256
 #endif
 #define PI_FLOW_RING 16
+#ifndef PI_FLOW_SLEEP
+#define PI_FLOW_SLEEP 1                                   // x 64 cycles between two polls of a wave
+#endif
 #define PI_FLOW_WAVES (PI_FLOW_BLOCK / 64)
 #define PI_FLOW_DEAD 0xFFFFFFFFu
 typedef unsigned long long PiGranule;                    // tag (high half) | float32 bits (low half)
 __device__ __forceinline__ unsigned int pi_flow_load32(const unsigned int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // sc1: never served by this CU's L1
 }
-template <bool LOCAL>
 __device__ __forceinline__ void pi_flow_store32(unsigned int* p, unsigned int v) {
-    if (LOCAL) *reinterpret_cast<volatile unsigned int*>(p) = v;                   // stays in the XCD's L2
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool LOCAL>
-__device__ __forceinline__ void pi_flow_store64(PiGranule* p, PiGranule v) {
-    if (LOCAL) *reinterpret_cast<volatile PiGranule*>(p) = v;
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // One wave reports that it has completed sweep k (its granules of version k have left: the caller has waited for its
 // vector-memory counter).  The last wave of the workgroup to do so publishes the workgroup's progress — after folding
 // the workgroup's residual maximum into checks[slot] when sweep k is one the residual is looked at.
-template <bool LOCAL>
 __device__ __forceinline__ void pi_flow_report(int k, bool look, int slot, float wave_max, unsigned int wg,
                                                unsigned int* lds_count, unsigned int* lds_max,
                                                unsigned int* __restrict__ progress, unsigned int* __restrict__ checks) {
@@ -960,7 +950,7 @@ __device__ __forceinline__ void pi_flow_report(int k, bool look, int slot, float
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    pi_flow_store32<LOCAL>(progress + wg, (unsigned int)(k + 1));
+    pi_flow_store32(progress + wg, (unsigned int)(k + 1));
 }
 // All W progress words and the status word behind them, one load per 64 words: the smallest progress, or PI_FLOW_DEAD
 // when the status word is raised.  Wave-uniform.
@@ -977,40 +967,25 @@ __device__ __forceinline__ unsigned int pi_flow_min_progress(const unsigned int*
     for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned int)__shfl_xor((int)m, o, 64));
     return __any(failed) ? PI_FLOW_DEAD : m;
 }
-template <bool LOCAL>
-__device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* __restrict__ policy,
-                                             const unsigned char* __restrict__ term, const float* __restrict__ tab,
-                                             float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
-                                             int check_interval, int* __restrict__ sweeps_out,
-                                             float* __restrict__ residual_log, PiGranule* __restrict__ ring,
-                                             unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
-                                             unsigned long long timeout_ticks, unsigned int W,
-                                             unsigned int* __restrict__ tickets) {
+extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
+pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                    const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
+                    int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
+                    PiGranule* __restrict__ ring, unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
+                    unsigned long long timeout_ticks) {
     __shared__ float lds_tab[PI_GRID.tab_len];
-    __shared__ unsigned int lds_count[32], lds_max[2], lds_wg, lds_seq, lds_bits;
+    __shared__ unsigned int lds_count[32], lds_max[2], lds_seq, lds_bits;
     constexpr unsigned int N = (unsigned int)PI_GRID.n;
+    const unsigned int W = gridDim.x, wg = blockIdx.x;
     const unsigned int tid = threadIdx.x, lane = tid & 63u;
     if (tid < 32u) lds_count[tid] = 0u;
     if (tid < 2u) lds_max[tid] = 0u;
     if (tid == 0u) {
         lds_seq = 0u;
         lds_bits = 0u;
-        unsigned int wg = blockIdx.x;
-        if (LOCAL) {                                       // participants: the first W workgroups that run on XCD 0
-            unsigned int xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            wg = PI_FLOW_DEAD;
-            if ((xcc & 15u) == 0u) {
-                const unsigned int t = atomicAdd(tickets, 1u);
-                if (t < W) wg = t;
-            }
-        }
-        lds_wg = wg;
     }
     pi_stage_table<PI_FLOW_BLOCK>(tab, lds_tab);
     __syncthreads();                                       // the only workgroup barrier of the kernel
-    const unsigned int wg = lds_wg;
-    if (wg == PI_FLOW_DEAD) return;                        // a spare workgroup, or one on another XCD
     const unsigned int s = wg * PI_FLOW_BLOCK + tid;
 
     // per state, once: 0 = no state (tail), 1 = terminal (keeps its value), 2 = done successor (no bootstrap), 3 = interpolates
@@ -1057,37 +1032,39 @@ __device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* 
             const unsigned int need = j + 2 > PI_FLOW_RING ? (unsigned int)(j + 2 - PI_FLOW_RING) : 0u;
             unsigned long long t0 = 0ull;
             unsigned int spins = 0u;
+            unsigned int missing = kind == 3u ? (unsigned int)((1ull << PI_C) - 1ull) : 0u;   // corners not yet seen at `want`
+#if PI_C > 32
+#error "the corner mask of the dataflow kernel holds 32 corners (2-D and 4-D grids)"
+#endif
             while (true) {
-                bool ok = true;
+                // a corner that has arrived stays valid until this wave has stored version j (flow control): only the
+                // missing ones are asked for again
                 PiGranule g[PI_C];
-                if (kind == 3u) {
 #pragma unroll
-                    for (int c = 0; c < PI_C; ++c)
-                        g[c] = __hip_atomic_load(src + base + (unsigned int)pi_corner_offset(c), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                }
+                for (int c = 0; c < PI_C; ++c)
+                    if (missing & (1u << c))
+                        g[c] = __hip_atomic_load(src + base + (unsigned int)pi_corner_offset(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (known < need || (spins & 255u) == 255u) {          // also: look at the status word now and then
                     const unsigned int m = pi_flow_min_progress(progress, W);
                     if (m == PI_FLOW_DEAD) { dead = true; break; }
                     known = m;
                 }
-                if (kind == 3u) {
 #pragma unroll
-                    for (int c = 0; c < PI_C; ++c) {
-                        ok = ok && (unsigned int)(g[c] >> 32) == want;
+                for (int c = 0; c < PI_C; ++c)
+                    if ((missing & (1u << c)) && (unsigned int)(g[c] >> 32) == want) {
                         v[c] = __uint_as_float((unsigned int)g[c]);
+                        missing &= ~(1u << c);
                     }
-                }
-                if (__all(ok) && known >= need) break;
+                if (__all(missing == 0u) && known >= need) break;
                 if (spins == 0u) t0 = wall_clock64();
                 else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
                 ++spins;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(PI_FLOW_SLEEP);
             }
             if (dead) break;
             if (reported < j) {                            // sweep j - 1: its store went out before this poll came back
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pi_flow_report<LOCAL>(j - 1, false, 0, 0.0f, wg, lds_count, lds_max, progress, checks);
+                pi_flow_report(j - 1, false, 0, 0.0f, wg, lds_count, lds_max, progress, checks);
                 reported = j;
             }
         }
@@ -1101,15 +1078,16 @@ __device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* 
         const float dlt = fabsf(nv - v_cur);               // 0 for lanes without a state
         v_cur = nv;
         if (kind != 0u)
-            pi_flow_store64<LOCAL>(ring + (size_t)(j % PI_FLOW_RING) * N + s,
-                                   ((PiGranule)(unsigned int)(j + 1) << 32) | (PiGranule)__float_as_uint(nv));
+            __hip_atomic_store(ring + (size_t)(j % PI_FLOW_RING) * N + s,
+                               ((PiGranule)(unsigned int)(j + 1) << 32) | (PiGranule)__float_as_uint(nv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         done_sweeps = j + 1;
         if (look) {
             // drain and report at once, then the one real barrier: every workgroup's maximum is in when its word says j + 1
             const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
             const float wave_max = pi_wave_max(dlt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pi_flow_report<LOCAL>(j, true, slot, wave_max, wg, lds_count, lds_max, progress, checks);
+            pi_flow_report(j, true, slot, wave_max, wg, lds_count, lds_max, progress, checks);
             reported = j + 1;
             ++looks;
             unsigned long long t0 = 0ull;
@@ -1152,7 +1130,7 @@ __device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* 
     }
     if (dead) {
         if (lane == 0u) {
-            pi_flow_store32<false>(progress + W, 1u + (unsigned int)done_sweeps);
+            pi_flow_store32(progress + W, 1u + (unsigned int)done_sweeps);
             *reinterpret_cast<volatile unsigned int*>(&lds_seq) = PI_FLOW_DEAD;
         }
         return;
@@ -1162,25 +1140,6 @@ __device__ __forceinline__ void pi_flow_body(float* __restrict__ Va, const int* 
         *sweeps_out = done_sweeps;
         if (delta_out != nullptr) *delta_out = residual;
     }
-}
-extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
-pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                    const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out, double theta,
-                    int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
-                    PiGranule* __restrict__ ring, unsigned int* __restrict__ progress, unsigned int* __restrict__ checks,
-                    unsigned long long timeout_ticks, unsigned int n_wgs, unsigned int* __restrict__ tickets) {
-    pi_flow_body<false>(Va, policy, term, tab, gamma, n_sweeps, delta_out, theta, check_interval, sweeps_out, residual_log, ring,
-                        progress, checks, timeout_ticks, n_wgs, tickets);
-}
-extern "C" __global__ void __launch_bounds__(PI_FLOW_BLOCK)
-pi_eval_flow_local_kernel(float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                          const float* __restrict__ tab, float gamma, int n_sweeps, float* __restrict__ delta_out,
-                          double theta, int check_interval, int* __restrict__ sweeps_out, float* __restrict__ residual_log,
-                          PiGranule* __restrict__ ring, unsigned int* __restrict__ progress,
-                          unsigned int* __restrict__ checks, unsigned long long timeout_ticks, unsigned int n_wgs,
-                          unsigned int* __restrict__ tickets) {
-    pi_flow_body<true>(Va, policy, term, tab, gamma, n_sweeps, delta_out, theta, check_interval, sweeps_out, residual_log, ring,
-                       progress, checks, timeout_ticks, n_wgs, tickets);
 }
 // Launched right behind a dataflow kernel: a wave may have given up while the others went through their last barrier,
 // so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
