@@ -79,11 +79,12 @@ SIGNATURES = {
     "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "pi_prepare_mask": (ctypes.c_int, [_vp, _vp, _vp]),
     "pi_prepare_mask_range": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
+    "pi_live_list": (ctypes.c_int64, [_vp, _vp, ctypes.c_int64, _vp]),
     "pi_eval_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "pi_eval_end": (ctypes.c_int, [_vp]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 _load_error: Exception | None = None
 
@@ -268,6 +269,14 @@ class Engine:
             _check(lib().pi_prepare_mask_range(self._h, term or None, int(s_begin), int(s_end), stream or None),
                    "pi_prepare_mask_range")
         return self.info(16)
+
+    def live_list(self, d_out=0, capacity=0, stream=0) -> int:
+        """Copy the live-state list into the device buffer at `d_out` (`capacity` int32 entries); returns its length
+        (0: the library keeps no list).  Without a buffer: the length only."""
+        m = int(lib().pi_live_list(self._h, d_out or None, int(capacity), stream or None))
+        if m < 0:
+            raise NativeError(f"pi_live_list failed: {last_error()}")
+        return m
 
     def eval_begin(self, policy, term, stream=0) -> int:
         """Start of one policy evaluation under the policy at `policy`: returns the length of the shorter list the

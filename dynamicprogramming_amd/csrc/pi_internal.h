@@ -111,7 +111,7 @@ struct pi_handle {
     hipFunction_t f_eval_push = nullptr, f_reach_pairs = nullptr;
     std::string dynamics_src, cache_dir; // what pi_compile was given (for the second module)
     bool has_cache_dir = false;
-    hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
+    hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_mask_list = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
                   f_probe_coords = nullptr, f_resident = nullptr;
     int num_cu = 0;

@@ -718,6 +718,41 @@ pi_scan_slots_kernel(unsigned long long* __restrict__ slots, long long count) {
     if (threadIdx.x == 0) slots[count] = carry;
 }
 
+// ---- the live-state list of pi_prepare_mask, built on the device ----------------------------------------------------
+// The non-terminal states of [s_begin, s_end) in ascending order, without the mask ever leaving the device (round 4 copied
+// it to the host and walked it there: 244 MB and a 244 M-iteration loop at 25^6).  Pass 0: every wave's ballot of "live"
+// is one word of the bitmap (word k covers states [w0 + 64 k, w0 + 64 k + 64), w0 = s_begin rounded down to 64; the host
+// keeps the bitmap — 1 bit per state — for the positions of arbitrary sub-ranges), and every 256-state block leaves
+// its count in a slot, packed with the number of its waves that have a live lane at all (high half: what the "is the
+// list worth it" test needs).  pi_scan_slots_kernel turns the counts into offsets; pass 1 repeats the ballots and writes
+// every live state at its block's offset + the live lanes before it.
+extern "C" __global__ void __launch_bounds__(PI_BLOCK)
+pi_mask_list_kernel(const unsigned char* __restrict__ term, long long s_begin, long long s_end, long long w0,
+                    unsigned long long* __restrict__ bits, unsigned long long* __restrict__ block_slots,
+                    int* __restrict__ out, int pass) {
+    __shared__ unsigned int wave_count[PI_BLOCK / 64];
+    const long long s = w0 + (long long)blockIdx.x * PI_BLOCK + threadIdx.x;
+    const bool live = s >= s_begin && s < s_end && !term[s];
+    const unsigned long long votes = __ballot(live);
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wave] = (unsigned int)__popcll(votes);
+    if (pass == 0 && lane == 0 && s < s_end) bits[(s - w0) >> 6] = votes;
+    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x == 0) {
+            unsigned long long total = 0ull;
+            for (int w = 0; w < PI_BLOCK / 64; ++w)
+                total += (unsigned long long)wave_count[w] + ((unsigned long long)(wave_count[w] != 0u) << 32);
+            block_slots[blockIdx.x] = total;
+        }
+    } else if (live) {
+        unsigned int before = (unsigned int)(block_slots[blockIdx.x] & 0xFFFFFFFFull);
+        for (unsigned int w = 0; w < wave; ++w) before += wave_count[w];
+        before += (unsigned int)__popcll(votes & ((1ull << lane) - 1ull));
+        out[before] = (int)s;
+    }
+}
+
 // ---- LDS-resident evaluation batch for small grids ----------------------------------------
 // Grids of a few thousand states (pi_create decides: up to 12 288 in 2-D, 4 096 in 4-D, 1 024 in
 // 6-D) are launch-bound: one sweep is a few microseconds of launch, load -> compute -> gather

@@ -104,6 +104,9 @@ class MountainCarCuda(CudaPolicyIteration2D):
     def _terminal_fn(self, states: np.ndarray):
         return (states[:, 0] >= 0.5) & (states[:, 1] >= 0.0), 0.0
 
+    def _terminal_fn_axes(self, axes):
+        return (axes[0] >= 0.5) & (axes[1] >= 0.0), 0.0
+
 
 class ContinuousMountainCarCuda(CudaPolicyIteration2D):
     """MountainCarContinuous-v0.  Follows runners/continuous_mountain_car_cuda.py:57-76
@@ -138,6 +141,9 @@ class ContinuousMountainCarCuda(CudaPolicyIteration2D):
 
     def _terminal_fn(self, states: np.ndarray):
         return (states[:, 0] >= 0.45) & (states[:, 1] >= 0.0), 0.0
+
+    def _terminal_fn_axes(self, axes):
+        return (axes[0] >= 0.45) & (axes[1] >= 0.0), 0.0
 
 
 # ═════════════════════════════ 4-D ═══════════════════════════════════════════════
@@ -199,6 +205,11 @@ class CartPoleCuda(CudaPolicyIteration4D):
         lim = self._TH_LIMIT
         return (x < -2.4) | (x > 2.4) | (th < -lim) | (th > lim), 0.0
 
+    def _terminal_fn_axes(self, axes):
+        x, th = axes[0], axes[2]
+        lim = self._TH_LIMIT
+        return (x < -2.4) | (x > 2.4) | (th < -lim) | (th > lim), 0.0
+
 
 class CartPoleSwingUpCuda(CudaPolicyIteration4D):
     """Cart-pole swing-up with an energy-shaped reward.  Follows
@@ -243,6 +254,10 @@ class CartPoleSwingUpCuda(CudaPolicyIteration4D):
 
     def _terminal_fn(self, states: np.ndarray):
         x = states[:, 0]
+        return (x < -2.4) | (x > 2.4), 0.0
+
+    def _terminal_fn_axes(self, axes):
+        x = axes[0]
         return (x < -2.4) | (x > 2.4), 0.0
 
 
@@ -525,6 +540,11 @@ class DoubleCartPoleCuda(CudaPolicyIteration6D):
         lim = self._TH_FAIL
         return ((x < -2.4) | (x > 2.4) | (t1 < -lim) | (t1 > lim) | (t2 < -lim) | (t2 > lim)), 0.0
 
+    def _terminal_fn_axes(self, axes):
+        x, t1, t2 = axes[0], axes[2], axes[4]
+        lim = self._TH_FAIL
+        return ((x < -2.4) | (x > 2.4) | (t1 < -lim) | (t1 > lim) | (t2 < -lim) | (t2 > lim)), 0.0
+
 
 class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
     """Double inverted pendulum swing-up on a cart.  Follows
@@ -595,6 +615,10 @@ class DoubleCartPoleSwingUpCuda(CudaPolicyIteration6D):
 
     def _terminal_fn(self, states: np.ndarray):
         x = states[:, 0]
+        return (x < -2.4) | (x > 2.4), 0.0
+
+    def _terminal_fn_axes(self, axes):
+        x = axes[0]
         return (x < -2.4) | (x > 2.4), 0.0
 
 

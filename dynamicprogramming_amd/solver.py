@@ -390,6 +390,46 @@ class _CudaPolicyIterationBase(abc.ABC):
         """(bool mask over grid nodes, scalar terminal value); default: no terminal states."""
         return np.zeros(len(states), dtype=bool), 0.0
 
+    def _terminal_fn_axes(self, axes):
+        """Optional, beyond the reference API: the same mask from the bin tables instead of the materialised (n, D)
+        grid.  `axes[d]` is dimension d's float32 bin table shaped to broadcast along dimension d (an open mesh, as
+        ``np.ix_`` builds it); return (bool array BROADCASTABLE to the grid's shape, scalar terminal value) — the
+        expression of ``_terminal_fn`` with ``states[:, d]`` replaced by ``axes[d]``.  The solver then builds the mask
+        on the device and never needs ``states_space`` (5.86 GB on the host for a 25^6 grid).  A class that only
+        defines ``_terminal_fn`` — every plugin written for the reference — is served through that hook as before."""
+        return NotImplemented
+
+    def _terminal_mask_on_device(self, dev):
+        """(uint8 device tensor of n states in MEMORY order or None when no node is terminal, terminal value, count)."""
+        import torch
+        cls = type(self)
+        definer = lambda name: next(c for c in cls.__mro__ if name in c.__dict__)     # noqa: E731
+        shape = [int(g) for g in self.grid_shape]
+        # the bin-table hook counts only when it is at least as derived as _terminal_fn: a subclass that overrides the
+        # reference hook of one of this package's envs must get ITS mask
+        if issubclass(definer("_terminal_fn_axes"), definer("_terminal_fn")):
+            axes = [b.reshape([-1 if k == d else 1 for k in range(self._D)]) for d, b in enumerate(self._bins)]
+            got = self._terminal_fn_axes(axes)
+            if got is not NotImplemented:
+                small, value = got
+                small = np.asarray(small, dtype=bool)
+                if not small.any():
+                    return None, float(value), 0
+                small = small.reshape((1,) * (self._D - small.ndim) + small.shape)
+                full = torch.from_numpy(np.ascontiguousarray(small)).to(dev).expand(shape)
+                if self._order is not None:
+                    full = full.permute(*self._order)
+                full = full.contiguous().reshape(-1).to(torch.uint8)
+                return full, float(value), int(full.sum().item())
+        if definer("_terminal_fn") is _CudaPolicyIterationBase:
+            return None, 0.0, 0
+        mask, value = self._terminal_fn(self.states_space)         # the reference's hook: needs the (n, D) array
+        mask = np.ascontiguousarray(mask, dtype=bool)
+        if not mask.any():
+            return None, float(value), 0
+        full = torch.from_numpy(np.ascontiguousarray(self._to_memory(mask.view(np.uint8)))).to(dev)
+        return full, float(value), int(mask.sum())
+
     # ── device state ────────────────────────────────────────────────────────────────
     def _allocate_tensors_and_compile(self) -> None:
         import torch
@@ -411,22 +451,17 @@ class _CudaPolicyIterationBase(abc.ABC):
         self._d_delta = torch.zeros(1, dtype=torch.float32, device=dev)
         self._d_changed = torch.zeros(1, dtype=torch.int32, device=dev)
 
-        overridden = type(self)._terminal_fn is not _CudaPolicyIterationBase._terminal_fn
-        if overridden:
-            terminal_mask, terminal_value = self._terminal_fn(self.states_space)
-            terminal_mask = np.ascontiguousarray(terminal_mask, dtype=bool)
-        else:
-            terminal_mask, terminal_value = None, 0.0
+        device_mask, terminal_value, n_terminal = self._terminal_mask_on_device(dev)
         self.d_terminal_mask = torch.zeros(n_pad, dtype=torch.uint8, device=dev)
-        if terminal_mask is not None and terminal_mask.any():
-            self.d_terminal_mask[:n] = torch.from_numpy(
-                np.ascontiguousarray(self._to_memory(terminal_mask.view(np.uint8)))).to(dev)
-            self.d_value_function[:n][self.d_terminal_mask[:n].bool()] = float(terminal_value)
-            logger.info(f"Terminal states: {int(terminal_mask.sum()):,} (value={terminal_value})")
+        if device_mask is not None:
+            self.d_terminal_mask[:n] = device_mask
+            del device_mask
+            self.d_value_function[:n].masked_fill_(self.d_terminal_mask[:n].bool(), float(terminal_value))
+            logger.info(f"Terminal states: {n_terminal:,} (value={terminal_value})")
         self.d_new_value_function.copy_(self.d_value_function)
         # What the sweeps are given as the mask: the tensor, or None when no grid node is terminal — the
         # kernels then stream neither the mask nor (on sweeps without a residual) the old values.
-        self._term_arg = self.d_terminal_mask if (terminal_mask is not None and terminal_mask.any()) else None
+        self._term_arg = self.d_terminal_mask if n_terminal > 0 else None
         # the mask is fixed from here on (as in the reference): the library may list the live states once
         # and visit only those in the later sweeps of an evaluation batch and in the improvement sweeps
         # (big grids whose terminal regions cut through many waves; a rank of a sharded run lists its own shard

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 8
+#define PI_MI355_ABI_VERSION 9
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -128,6 +128,10 @@ int pi_eval_sweeps(pi_handle* h, float* Va, float* Vb, const int32_t* policy,
  */
 int pi_prepare_mask(pi_handle* h, const uint8_t* d_term, void* stream);
 int pi_prepare_mask_range(pi_handle* h, const uint8_t* d_term, int64_t s_begin, int64_t s_end, void* stream);
+/* The list pi_prepare_mask built (ascending flat indices of the non-terminal states of the listed range), copied into
+ * d_out (device, `capacity` entries) on `stream`; returns its length (0: no list is in use; d_out == NULL: length only;
+ * -1: error).  For inspection and tests: the sweeps use the list inside the library. */
+int64_t pi_live_list(pi_handle* h, int32_t* d_out, int64_t capacity, void* stream);
 
 /*
  * Optional bracket around one policy_evaluation (:300-336), for handles with a live-state list: under a FIXED

@@ -1278,3 +1278,87 @@ def test_recovery_after_an_abandoned_sharded_batch(cuda_device, monkeypatch):
         t.join(timeout=300)
     assert not errors, errors
     assert out == [True] * world
+
+
+@pytest.mark.parametrize("name,shape,rng_lo,rng_hi", [("cartpole", (11, 9, 13, 8), None, None),
+                                                      ("double_cartpole", (6, 5, 7, 5, 6, 7), 1003, 70001),
+                                                      ("cartpole", (11, 9, 13, 8), 64, 4097),
+                                                      ("cartpole", (11, 9, 13, 8), 7, 7 + 64)])
+def test_live_state_list_is_built_on_the_device(name, shape, rng_lo, rng_hi, cuda_device, monkeypatch):
+    """pi_prepare_mask / pi_prepare_mask_range build the list with count -> scan -> ordered-write kernels (no host
+    pass over the mask): the list equals the ascending non-terminal states of the range — whole grid, a ragged shard
+    whose borders are not multiples of 64, ranges inside one block — and nothing is listed when no lane would idle."""
+    torch = _torch()
+    monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
+    cls = envs.ENVS[name]
+    bins = H.env_bins(name, shape)
+    eng = _native.Engine(cls._D, [len(b) for b in bins], [b.min() for b in bins], [b.max() for b in bins], bins,
+                         np.asarray(cls.ACTIONS, np.float32), device=cuda_device.index or 0)
+    eng.compile(envs.dynamics_source(name))
+    eng.set_option(6, 1)                                      # keep the list whatever it saves: this test reads it
+    states = oracle.states_from_bins(bins)
+    term, _ = H.terminal_mask(name, states)
+    n = len(states)
+    d_term = torch.from_numpy(term.astype(np.uint8)).to(cuda_device)
+    a, b = (0, n) if rng_lo is None else (rng_lo, min(rng_hi, n))
+    count = eng.prepare_mask(d_term.data_ptr(), 0, a, b) if rng_lo is not None else eng.prepare_mask(d_term.data_ptr())
+    want = np.flatnonzero(~term[a:b]).astype(np.int32) + a
+    assert count == len(want) > 0
+    out = torch.full((count + 3,), -1, dtype=torch.int32, device=cuda_device)
+    assert eng.live_list(out.data_ptr(), count + 3) == count
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:count], want) and np.all(got[count:] == -1)
+    # the positions the library derives from its bitmap: a sub-range sweep over the list equals the state-order sweep
+    V = torch.randn(n, dtype=torch.float32, device=cuda_device)
+    V[d_term.bool()] = 0.0
+    pol = torch.randint(0, len(cls.ACTIONS), (n,), dtype=torch.int32, device=cuda_device)
+    lo2, hi2 = a + (b - a) // 3, b - (b - a) // 5
+    with_list = [V.clone(), V.clone()]
+    eng.eval_sweeps(with_list[0].data_ptr(), with_list[1].data_ptr(), pol.data_ptr(), d_term.data_ptr(), lo2, hi2, 0.99, 3, 0)
+    eng.prepare_mask(0)
+    assert eng.live_list() == 0
+    plain = [V.clone(), V.clone()]
+    eng.eval_sweeps(plain[0].data_ptr(), plain[1].data_ptr(), pol.data_ptr(), d_term.data_ptr(), lo2, hi2, 0.99, 3, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(with_list[0].view(torch.int32), plain[0].view(torch.int32))
+    assert torch.equal(with_list[1].view(torch.int32), plain[1].view(torch.int32))
+    # without the "keep it anyway" option a mask that leaves no lane idle is not listed
+    eng.set_option(6, 0)
+    none = torch.zeros(n, dtype=torch.uint8, device=cuda_device)
+    none[: (n // 64) * 32] = 1                                 # whole waves terminal: no partly idle wave
+    assert eng.prepare_mask(none.data_ptr()) == 0
+    eng.close()
+
+
+def test_live_state_list_of_the_full_c5_grid_is_the_sorted_set_of_live_states(cuda_device):
+    """25^6 = 244 140 625 states, 35 % terminal, in the solver's own memory order: the device-built list is exactly the
+    ascending set of non-terminal states (torch.nonzero of the mask), and building the solver no longer materialises
+    the (n, 6) grid on the host (the mask comes from the bin tables: _terminal_fn_axes)."""
+    import time
+    torch = _torch()
+    t0 = time.perf_counter()
+    solver = envs.make("double_cartpole", 25, device=cuda_device)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    print(f"envs.make('double_cartpole', 25): {seconds:.1f} s (round 4: host-built mask and list)")
+    assert solver._states_space is None
+    eng = solver._backend.engine
+    n = solver.n_states
+    count = eng.live_list()
+    assert count == eng.info(16) > 0
+    out = torch.empty(count, dtype=torch.int32, device=cuda_device)
+    assert eng.live_list(out.data_ptr(), count) == count
+    want = torch.nonzero(solver.d_terminal_mask[:n] == 0).reshape(-1).to(torch.int32)
+    assert want.numel() == count and torch.equal(out, want)
+    # the mask itself against the reference's hook, evaluated on the bin tables of a few whole planes
+    bins = solver._bins
+    lim = envs.DoubleCartPoleCuda._TH_FAIL
+    x_bad, t1_bad, t2_bad = np.abs(bins[0]) > 2.4, np.abs(bins[2]) > lim, np.abs(bins[4]) > lim
+    user = solver._to_user(solver.d_terminal_mask[:n]).reshape([25] * 6)
+    assert int(user.sum().item()) == n - count
+    assert bool(user[torch.from_numpy(x_bad)].all()) and bool(user[:, :, torch.from_numpy(t1_bad)].all())
+    assert bool(user[:, :, :, :, torch.from_numpy(t2_bad)].all())
+    keep = user[torch.from_numpy(~x_bad)][:, :, torch.from_numpy(~t1_bad)][:, :, :, :, torch.from_numpy(~t2_bad)]
+    assert not bool(keep.any())
+    solver._backend.close()

@@ -374,3 +374,44 @@ def test_exchange_planner_sends_exactly_what_is_reachable(world, g0, stride0, da
             need[p * stride0:min((p + 1) * stride0, n)] = True
         need[dst * per:min((dst + 1) * per, n)] = False                             # its own shard does not travel
         assert np.array_equal(got[dst] > 0, need) and got[dst].max(initial=0) <= 1
+
+
+AXES_ENVS = [("mountain_car", (40, 30)), ("continuous_mountain_car", (33, 21)), ("cartpole", (9, 5, 11, 4)),
+             ("cartpole_swingup", (9, 4, 6, 3)), ("double_cartpole", (9, 3, 7, 2, 7, 3)),
+             ("double_cartpole_swingup", (9, 2, 3, 2, 3, 2))]
+
+
+@pytest.mark.parametrize("name,shape", AXES_ENVS)
+@pytest.mark.parametrize("order", [None, "reversed"])
+def test_terminal_mask_from_bin_tables_equals_the_reference_hook(name, shape, order, monkeypatch):
+    """`_terminal_fn_axes` (the mask from the bin tables, built on the device: no (n, D) array) gives exactly the mask
+    of the reference's `_terminal_fn(states_space)` hook (:127-138) — also when the device arrays live in another
+    memory order — and the solver does not touch `states_space` for it."""
+    cls = envs.ENVS[name]
+    D = cls._D
+    if order == "reversed":
+        monkeypatch.setenv("PI_MI355_ORDER", ",".join(str(d) for d in reversed(range(D))))
+    s = _solver(name, shape)
+    assert s._states_space is None                                      # never materialised
+    want, value = cls._terminal_fn(s, s.states_space)
+    assert want.any() and not want.all()
+    got = s._to_user(s.d_terminal_mask[: s.n_states].numpy())
+    assert np.array_equal(got.astype(bool), np.asarray(want, bool))
+    assert s._mask_arg() is s.d_terminal_mask
+    tv = s._to_user(s.d_value_function[: s.n_states].numpy())
+    assert np.all(tv[want] == np.float32(value)) and np.all(tv[~want] == 0.0)
+
+
+def test_a_subclass_that_overrides_the_reference_hook_gets_its_own_mask():
+    """A plugin written for the reference overrides `_terminal_fn` only: the bin-table hook of the class it derives
+    from must not shadow it; and a class without any terminal hook has no mask."""
+    class Narrow(envs.CartPoleSwingUpCuda):
+        def _terminal_fn(self, states):
+            return np.abs(states[:, 0]) > 1.0, -3.0
+    bins = H.env_bins_space("cartpole_swingup", (9, 4, 6, 3))
+    s = H.with_checker_backend(Narrow)(bins, Narrow.ACTIONS, CudaPIConfig(**Narrow.CONFIG))
+    want = np.abs(s.states_space[:, 0]) > 1.0
+    assert np.array_equal(s.d_terminal_mask[: s.n_states].numpy().astype(bool), want)
+    assert np.all(s.d_value_function[: s.n_states].numpy()[want] == np.float32(-3.0))
+    p = _solver("pendulum", (12, 12))
+    assert p._mask_arg() is None and not p.d_terminal_mask.any()
