@@ -1283,7 +1283,7 @@ def test_recovery_after_an_abandoned_sharded_batch(cuda_device, monkeypatch):
 @pytest.mark.parametrize("name,shape,rng_lo,rng_hi", [("cartpole", (11, 9, 13, 8), None, None),
                                                       ("double_cartpole", (6, 5, 7, 5, 6, 7), 1003, 70001),
                                                       ("cartpole", (11, 9, 13, 8), 64, 4097),
-                                                      ("cartpole", (11, 9, 13, 8), 7, 7 + 64)])
+                                                      ("cartpole", (11, 9, 13, 8), -7, 64)])
 def test_live_state_list_is_built_on_the_device(name, shape, rng_lo, rng_hi, cuda_device, monkeypatch):
     """pi_prepare_mask / pi_prepare_mask_range build the list with count -> scan -> ordered-write kernels (no host
     pass over the mask): the list equals the ascending non-terminal states of the range — whole grid, a ragged shard
@@ -1300,6 +1300,8 @@ def test_live_state_list_is_built_on_the_device(name, shape, rng_lo, rng_hi, cud
     term, _ = H.terminal_mask(name, states)
     n = len(states)
     d_term = torch.from_numpy(term.astype(np.uint8)).to(cuda_device)
+    if rng_lo is not None and rng_lo < 0:                     # a range inside one or two 64-state blocks in mid-grid
+        rng_lo, rng_hi = n // 2 - rng_lo, n // 2 - rng_lo + rng_hi
     a, b = (0, n) if rng_lo is None else (rng_lo, min(rng_hi, n))
     count = eng.prepare_mask(d_term.data_ptr(), 0, a, b) if rng_lo is not None else eng.prepare_mask(d_term.data_ptr())
     want = np.flatnonzero(~term[a:b]).astype(np.int32) + a
