@@ -656,7 +656,23 @@ int pi_exchange_plan(pi_handle* h, const uint8_t* term, int64_t per, int mode, i
         if (pos < plan->s_end) plan->interior.push_back({pos, plan->s_end});
         // ---- what a transport that can deliver from inside the sweep (can_push) adds to the plan --------------------
         const char* fused_env = std::getenv("PI_MI355_P2P_FUSED");
-        const bool fused_wanted = c->can_push() && !(fused_env && std::atoi(fused_env) == 0) && pi::ensure_push_module(h) == 0;
+        bool fused_wanted = c->can_push() && !(fused_env && std::atoi(fused_env) == 0) && pi::ensure_push_module(h) == 0;
+        if (c->can_push()) {
+            // every rank must take the fused branches below or none: a rank whose second module did not build (a failed
+            // hipRTC compile, a corrupt cache entry) would otherwise leave its peers waiting in the pair probe until the
+            // communicator's time limit.  One scalar sum: fused only if it is wanted everywhere.
+            uint32_t* d_votes = nullptr;
+            PI_HIP(hipMalloc((void**)&d_votes, sizeof(uint32_t)));
+            const uint32_t mine = fused_wanted ? 1u : 0u;
+            uint32_t all = 0;
+            hipError_t e = hipMemcpyAsync(d_votes, &mine, sizeof mine, hipMemcpyHostToDevice, st);
+            int rc = e == hipSuccess ? c->allreduce_sum_u32(d_votes, st) : 1;
+            if (!rc && hipMemcpyAsync(&all, d_votes, sizeof all, hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+            if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+            (void)hipFree(d_votes);
+            if (rc) return fail("exchange plan: the ranks could not agree on the fused exchange");
+            fused_wanted = all == (uint32_t)c->world;
+        }
         // Pair refinement.  With the velocity that moves coordinate 0 somewhere else than in memory dimension 1 (the fast
         // single-GPU orders put it along the lanes) the rows (i0, i1) above are all reachable and the segments are whole
         // bands of planes; the fused exchange delivers per STATE, so the destination masks below are cut down to the
