@@ -195,9 +195,6 @@ class _CudaPolicyIterationBase(abc.ABC):
     # (csrc/pi_push_kernels.hip: pi_reach_pairs_kernel).  None: the env's own order (what RCCL-sharded solvers keep).
     SHARDED_MEMORY_ORDER = None
     _ORDER_MIN_STATES = 1 << 22
-    # Sweep backend class.  Private: the product has exactly one (the HIP backend); the CPU test-suite
-    # swaps a checker in here to exercise the host logic without a GPU (tests/helpers.py).
-    _sweep_backend_cls = None
 
     def __init__(self, bins_space: dict, action_space, config: CudaPIConfig | None = None, *,
                  device=None, process_group=None, transport=None) -> None:
@@ -212,7 +209,7 @@ class _CudaPolicyIterationBase(abc.ABC):
                        bootstrapped over `process_group`, when torch.distributed is initialised;
                        False = stay single-rank even then
         """
-        if self._sweep_backend_cls is None and not GPU_AVAILABLE:
+        if not GPU_AVAILABLE:
             raise RuntimeError(
                 f"{type(self).__name__} needs libpi_mi355.so and a ROCm GPU (MI355X, gfx950): "
                 + (_native_reason() or "torch.cuda.is_available() is False"))
@@ -434,11 +431,10 @@ class _CudaPolicyIterationBase(abc.ABC):
     def _allocate_tensors_and_compile(self) -> None:
         import torch
         logger.info("Allocating device tensors and compiling gfx950 kernels...")
-        factory = self._sweep_backend_cls or HipSweepBackend
         kw = {} if self._order is None else {"order": self._order}
-        self._backend = factory(self._D, self.grid_shape, self.bounds_low, self.bounds_high,
-                                self._bins, self.action_space, self._dynamics_cuda_src(),
-                                device=self._device_arg, **kw)
+        self._backend = HipSweepBackend(self._D, self.grid_shape, self.bounds_low, self.bounds_high,      # the one backend
+                                        self._bins, self.action_space, self._dynamics_cuda_src(),
+                                        device=self._device_arg, **kw)
         if self._order is not None:
             logger.info(f"memory order of the dimensions: {[self._bin_keys[d] for d in self._order]}")
         dev = self._backend.device

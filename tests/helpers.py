@@ -84,9 +84,18 @@ def oracle_for(name: str, libm: bool = False) -> oracle.OracleLib:
 
 def with_checker_backend(cls):
     """Subclass of a solver class whose sweeps run on the CPU checker below instead of the HIP
-    backend — for HOST-LOGIC tests only.  The hook is the private class attribute
-    ``_sweep_backend_cls``; the product never sets it."""
-    return type(cls.__name__ + "OnChecker", (cls,), {"_sweep_backend_cls": OracleSweepBackend})
+    backend — for HOST-LOGIC tests only.  The product has exactly one backend and offers no hook to
+    swap it: while such a solver is being constructed the test patches the module's own names
+    (``solver.HipSweepBackend``, ``solver.GPU_AVAILABLE``) and restores them afterwards."""
+    def __init__(self, *args, **kwargs):
+        from dynamicprogramming_amd import solver as S
+        saved = (S.HipSweepBackend, S.GPU_AVAILABLE)
+        S.HipSweepBackend, S.GPU_AVAILABLE = OracleSweepBackend, True
+        try:
+            cls.__init__(self, *args, **kwargs)
+        finally:
+            S.HipSweepBackend, S.GPU_AVAILABLE = saved
+    return type(cls.__name__ + "OnChecker", (cls,), {"__init__": __init__})
 
 
 class OracleSweepBackend:

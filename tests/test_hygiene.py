@@ -38,7 +38,12 @@ def test_product_has_one_backend_and_no_test_transport():
     from dynamicprogramming_amd.solver import _CudaPolicyIterationBase
     params = inspect.signature(_CudaPolicyIterationBase.__init__).parameters
     assert list(params) == ["self", "bins_space", "action_space", "config", "device", "process_group", "transport"]
-    assert _CudaPolicyIterationBase._sweep_backend_cls is None
+    # no seam at all: the class has no attribute through which another backend could be installed (the CPU tests patch
+    # the module's own names while they construct a solver: tests/helpers.py)
+    assert not any("backend_cls" in name or "backend_factory" in name for name in dir(_CudaPolicyIterationBase))
+    import dynamicprogramming_amd.solver as S
+    src = Path(S.__file__).read_text()
+    assert src.count("HipSweepBackend(") == 1 and "_sweep_backend_cls" not in src
 
 
 def test_no_reference_derived_artifacts_in_the_tree():
