@@ -128,12 +128,12 @@ struct pi_handle {
     // Dataflow evaluation (pi_eval_flow_kernel): launch-bound grids that do not fit one CU's LDS run a whole policy
     // evaluation in one launch, the iterates travelling between workgroups as tagged granules.  flow: this grid
     // qualifies; f_flow is null when the occupancy query does not admit all workgroups at once.  d_flow: ring of 16
-    // granule versions | progress words + status | check slots (owned; sized for flow_sweeps sweeps).
+    // granule versions | progress words + status | check slots (owned; flow_bytes).
     bool flow = false;
     int flow_block = 256;
     hipFunction_t f_flow = nullptr, f_flow_finish = nullptr;
     void* d_flow = nullptr;
-    int flow_sweeps = 0;
+    size_t flow_bytes = 0;
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     // pi_prepare_mask: the non-terminal states of the mask at live_term, ascending (device, owned); in use only

@@ -954,3 +954,71 @@ def test_memory_order_auto_picks_a_lane_dimension_from_the_dynamics(name, bins, 
                                  max_eval_iter=cfg.max_eval_iter, max_pi_iter=cfg.max_pi_iter, terminal_value=tval)
     H.assert_bits_equal(s.value_function, ref["value_function"], f"{name} auto order {order}")
     assert np.array_equal(s.policy, ref["policy"]) and s.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
+
+
+@pytest.mark.parametrize("name,bins", [("pendulum", 200), ("cartpole", 15), ("pendulum", 50)])
+@pytest.mark.parametrize("interval,max_sweeps", [(1, 37), (7, 60), (25, 26), (25, 1)])
+def test_one_launch_evaluation_with_any_look_interval(name, bins, interval, max_sweeps, cuda_device):
+    """pi_policy_evaluation (dataflow kernel on the 200 x 200 and 15^4 grids, LDS-resident on 50 x 50) looks at the
+    residual on sweeps 0, k, 2k, ... and the last one for ANY interval k — every sweep (k = 1: the control block holds one
+    slot per look and grows with it), an interval that does not divide the limit, a single sweep — and stops at the first
+    look below theta: sweeps done, every residual looked at and V equal the same schedule driven sweep by sweep."""
+    torch = _torch()
+    s = envs.make(name, bins, device=cuda_device)
+    eng = s._backend.engine
+    assert s._backend.resident
+    n = s.n_states
+    gamma = float(np.float32(0.9))
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32).to(cuda_device)
+    term = s._mask_arg()
+    if term is not None:
+        V0[term[:n].bool()] = 0.0
+    pol = torch.randint(0, s.n_actions, (n,), generator=gen, dtype=torch.int32).to(cuda_device)
+    theta = 0.05
+    for rounds in range(2):                              # twice: the second evaluation reuses the control block
+        V = V0.clone()
+        sweeps, looked = s._backend.policy_evaluation(V, pol, term, gamma, theta, max_sweeps, interval)
+        A, B = V0.clone(), V0.clone()
+        d = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+        want_looked, done = [], 0
+        for i in range(max_sweeps):
+            look = i % interval == 0 or i == max_sweeps - 1
+            eng.eval_sweep(A.data_ptr(), B.data_ptr(), pol.data_ptr(), s._backend._ptr(term), 0, n, gamma,
+                           d.data_ptr() if look else 0)
+            A, B = B, A
+            done = i + 1
+            if look:
+                want_looked.append(np.float32(d.item()))
+                if want_looked[-1] < theta:
+                    break
+        assert sweeps == done
+        H.assert_bits_equal(np.asarray(looked, np.float32), np.asarray(want_looked, np.float32), "residuals looked at")
+        H.assert_bits_equal(V.cpu().numpy(), A.cpu().numpy(), "V after the evaluation")
+    s._backend.close()
+
+
+def test_one_launch_evaluation_gives_up_loudly_instead_of_hanging(cuda_device, monkeypatch):
+    """Every device-side wait of the dataflow kernel is bounded: with a time limit no hand-off can meet (100 ns) a wave
+    gives up, raises the status word, every other wave leaves at its next poll, the launch ENDS, *d_sweeps = -1 and
+    the solver raises — and the next evaluation with a sane limit is unaffected."""
+    torch = _torch()
+    s = envs.make("pendulum", 200, device=cuda_device)
+    assert s._backend.engine.info(19) > 0
+    monkeypatch.setenv("PI_MI355_FLOW_TIMEOUT", "0.0000001")
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        s.policy_evaluation()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("PI_MI355_FLOW_TIMEOUT")
+    s.d_value_function.zero_()
+    s.d_new_value_function.zero_()
+    delta = s.policy_evaluation()
+    ref = envs.make("pendulum", 200, device=cuda_device)
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    plain = envs.make("pendulum", 200, device=cuda_device)
+    assert not plain._backend.resident
+    want = plain.policy_evaluation()
+    assert np.float32(delta) == np.float32(want) and s.stats["sweeps_per_iter"][-1] == plain.stats["sweeps_per_iter"][-1]
+    assert torch.equal(s.d_value_function.view(torch.int32), plain.d_value_function.view(torch.int32))
+    for x in (s, ref, plain):
+        x._backend.close()
