@@ -340,7 +340,7 @@ EXTRA_CONFIGS = [
 ]
 # rough wall seconds an extra config needs on a GPU box (construction incl. the terminal hook and the live list, the
 # timed steps, the state transfer): what the time budget is checked against before it starts
-EXTRA_COST_S = {"c2": 6.0, "c3": 8.0, "c5": 60.0, "c5_swingup": 60.0}
+EXTRA_COST_S = {"c2": 5.0, "c3": 6.0, "c5": 20.0, "c5_swingup": 20.0}   # measured: 0.1 / 0.2 / 1.8 / 1.9 s with a warm kernel cache
 
 
 def measure_extra_config(label: str, env: str, bins: int, steps: int, warmup: int, dev, khash: str) -> dict:
