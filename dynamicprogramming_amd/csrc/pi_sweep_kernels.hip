@@ -1176,6 +1176,277 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
         if (delta_out != nullptr) *delta_out = residual;
     }
 }
+// ---- XCD-local evaluation: a whole policy evaluation on the CUs of ONE XCD, hand-off through that XCD's L2 -------------
+// The dataflow kernel above pays one trip through the fabric per sweep (2.8 us on MI355X) because its workgroups may
+// run anywhere.  A grid of a few ten thousand states does not need the whole chip: this kernel runs the evaluation on
+// the 32 CUs of ONE XCD (one workgroup of 1 024 threads per CU, up to 2 states per thread: 2^16 states), whose L2 all of them share, with a real
+// barrier between the Jacobi sweeps that never leaves that L2:
+//   * successor cell, fractional offsets and reward of a thread's states stay in registers (the policy is fixed);
+//   * sweep j gathers its 2^D corners from version j - 1 of V with PLAIN loads and stores version j with PLAIN stores:
+//     a plain store stops in the XCD's L2 and a load that misses the CU's L1 is served from there;
+//   * the L1 is the one thing that could serve a stale value, so no address is read twice without an L1 invalidate in
+//     between: versions live in a ring of PI_XCD_RING buffers (memory is plentiful: 128 x 4 n bytes <= 32 MB), version j
+//     in slot j % RING, and at the start of every sweep j with j % RING == 0 every workgroup invalidates its CU's L1
+//     (buffer_inv sc1, ~1.7 us per 128 sweeps).  Between two reads of an address by one CU there is always exactly
+//     one such invalidate, and an address is never read before the barrier behind its store;
+//   * the barrier: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets, thread 0 stores the workgroup's
+//     8-byte granule {sweep number + 1, bits of the workgroup's residual maximum} with a PLAIN store (it stops in the
+//     L2), and wave 0 polls the granules of all W <= 64 workgroups — one wave-wide 8-byte load that bypasses the L1
+//     (sc1; served by the L2: four lines) — until every one carries this sweep's number: one store and one load round
+//     trip inside the XCD instead of a fabric hop.  Two banks of granules (sweep parity): a workgroup that runs ahead
+//     writes the other bank.  The residual of a look is the maximum over the granules: all workgroups stop together.
+//     What does NOT work here, measured (profiles/r05/negative_results.txt (1)): polling with a non-temporal load — it is
+//     served by the CU's L1 once the line is there (37 of 40 workgroups spun on a stale count); a counter of atomic
+//     adds polled with returning atomics — correct, but gfx950 performs device-scope atomics on the memory side of the
+//     fabric: 3.1 us per sweep, worse than the dataflow kernel's hop.
+// HIP promises nothing about where a workgroup runs, so nothing is assumed: the host launches spare workgroups; each reads
+// its XCC id from the hardware register; the first W that find themselves on XCD 0 take a ticket and take part, the
+// others leave at once.  Too few on XCD 0 or a wait that runs out (timeout_ticks) raise the status word: every
+// workgroup leaves, and pi_xcd_finish_kernel — the ONLY writer of V and *sweeps_out — reports *sweeps_out < 0 with V
+// untouched; the host then runs the evaluation again with the placement-independent dataflow kernel.
+// Arithmetic identical to pi_eval_sweep_kernel's: same bits, residuals, sweep counts.
+#ifndef PI_XCD
+#define PI_XCD 0
+#endif
+#if PI_XCD
+#define PI_XCD_BLOCK 1024
+#ifndef PI_XCD_TIMING
+#define PI_XCD_TIMING 0
+#endif
+#ifndef PI_XCD_RING
+#define PI_XCD_RING 128
+#endif
+#define PI_XCD_CTL_STATUS 64                              // control words (on lines of their own): 0 tickets
+#define PI_XCD_CTL_DONE 80                                // sweeps done, residual bits (written by workgroup 0 at the end)
+#define PI_XCD_CTL_GRANULES 128                            // 2 banks x 64 granules of 8 bytes (256 words)
+#define PI_XCD_CTL_WORDS (PI_XCD_CTL_GRANULES + 256)
+#define PI_XCD_NPAD (((unsigned int)PI_GRID.n + 31u) & ~31u)      // floats per version: whole 128-byte lines
+// The 2^D corner values with loads that are never served by this CU's L1 (sc1: the L2 answers), issued back to back;
+// pi_xcd_wait() is the one wait for all of them.  Written as instructions: a pair is only 4-byte aligned, which the
+// hardware loads in one global_load_dwordx2 and C++ has no atomic type for.
+__device__ __forceinline__ void pi_xcd_request_corners(const float* V, unsigned int base, PiPair (&vp)[PI_NPAIR]) {
+    constexpr int kNear = 1 << (PI_D - 2);
+#pragma unroll
+    for (int m = 0; m < kNear; ++m) {
+        int far = 0;
+#pragma unroll
+        for (int d = 0; d < PI_D - 2; ++d) far += ((m >> d) & 1) * PI_GRID.stride[d];
+        const float* p = V + (base + (unsigned int)far);
+        const float* q = p + PI_GRID.stride[PI_D - 2];
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(vp[m]) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(vp[m | kNear]) : "v"(q) : "memory");
+    }
+}
+template <int K>
+__device__ __forceinline__ void pi_xcd_wait(PiPair (&vp)[K][PI_NPAIR]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int m = 0; m < PI_NPAIR; ++m) asm volatile("" : "+v"(vp[k][m]));      // nothing reads a pair above the wait
+}
+// One workgroup per CU (PI_XCD_PAD floats of LDS that nothing else needs see to it), PI_XCD_S states per workgroup —
+// the host's choice: n over the XCD's 32 CUs, rounded up to whole 128-byte lines — i.e. PI_XCD_K = ceil(S / 1024) states
+// per thread: every CU carries the same load and the barrier waits for nobody in particular.
+#ifndef PI_XCD_S
+#define PI_XCD_S 1024
+#endif
+#define PI_XCD_K ((PI_XCD_S + PI_XCD_BLOCK - 1) / PI_XCD_BLOCK)
+#define PI_XCD_W (((unsigned int)PI_GRID.n + PI_XCD_S - 1u) / PI_XCD_S)
+#define PI_XCD_PAD 21504                                  // 84 KB: more than half a CU's LDS
+extern "C" __global__ void __launch_bounds__(PI_XCD_BLOCK)
+pi_eval_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+                   const float* __restrict__ tab, float gamma, int n_sweeps, double theta, int check_interval,
+                   float* __restrict__ residual_log, float* ring, unsigned int* ctl, unsigned long long timeout_ticks) {
+    constexpr unsigned int N = (unsigned int)PI_GRID.n, W = PI_XCD_W;
+    static_assert(W <= 64u, "one wave polls the granules of all workgroups");
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ float lds_red[PI_XCD_BLOCK / 64];
+    __shared__ unsigned int lds_wg, lds_ok, lds_bits;
+    __shared__ float lds_pad[PI_XCD_PAD];
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    if (n_sweeps < 0) {                                    // never: keeps the allocation
+        for (unsigned int i = tid; i < PI_XCD_PAD; i += PI_XCD_BLOCK) lds_pad[i] = gamma;
+        __syncthreads();
+        residual_log[tid] = lds_pad[(tid * 21u + 1u) % PI_XCD_PAD];
+    }
+    if (tid == 0u) {
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned int wg = PI_FLOW_DEAD;
+        if ((xcc & 15u) == 0u) {
+            const unsigned int t = atomicAdd(ctl, 1u);
+            if (t < W) wg = t;
+        }
+        lds_wg = wg;
+        lds_ok = 1u;
+        lds_bits = 0u;
+    }
+    pi_stage_table<PI_XCD_BLOCK>(tab, lds_tab);
+    __syncthreads();
+    const unsigned int wg = lds_wg;
+    if (wg == PI_FLOW_DEAD) return;                        // a spare workgroup, or one on another XCD
+    const unsigned int s0 = wg * (unsigned int)PI_XCD_S + tid;
+    const unsigned int s_end = min(N, (wg + 1u) * (unsigned int)PI_XCD_S);
+
+    // per state, once: 0 = no state (tail), 1 = terminal (keeps its value), 2 = done successor (no bootstrap), 3 = interpolates
+    unsigned int kind[PI_XCD_K], base[PI_XCD_K];
+    float fr[PI_XCD_K][PI_D], reward[PI_XCD_K], v_cur[PI_XCD_K];
+#pragma unroll
+    for (int k = 0; k < PI_XCD_K; ++k) {
+        const unsigned int s = s0 + (unsigned int)k * PI_XCD_BLOCK;
+        kind[k] = 0u;
+        base[k] = 0u;
+        reward[k] = 0.0f;
+        v_cur[k] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < PI_D; ++d) fr[k][d] = 0.0f;
+        if (s < s_end) {
+            v_cur[k] = Va[s];
+            kind[k] = 1u;
+            if (term == nullptr || !term[s]) {
+                float x[PI_D], ns[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                bool done;
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + pi_checked_action(policy[s], s)], ns, &reward[k], &done);
+                kind[k] = 2u;
+                if (!done) {
+                    pi_locate(ns, base[k], fr[k]);
+                    kind[k] = 3u;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                // one state at a time
+    }
+    unsigned int* status = ctl + PI_XCD_CTL_STATUS;
+    PiGranule* granules = reinterpret_cast<PiGranule*>(ctl + PI_XCD_CTL_GRANULES);
+    int done_sweeps = 0;
+    float residual = 0.0f;
+    bool dead = false;                                     // workgroup-uniform
+#if PI_XCD_TIMING
+    unsigned long long tacc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, tp = __builtin_readcyclecounter();
+#define PI_XCD_STAMP(k) do { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tp; tp = tn; } while (0)
+#else
+#define PI_XCD_STAMP(k)
+#endif
+    for (int j = 0; j < n_sweeps; ++j) {
+        const float* src = j == 0 ? Va : ring + (size_t)((j - 1) & 1) * PI_XCD_NPAD;
+        float* dst = ring + (size_t)(j & 1) * PI_XCD_NPAD;
+        const bool last = j == n_sweeps - 1;
+        const bool look = last || j % check_interval == 0;
+        const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
+        // states that do not interpolate read cell 0 (their `base`) and drop the result: no divergence around the loads,
+        // and the gathers of a thread's states are in flight together
+        PiPair vp[PI_XCD_K][PI_NPAIR];
+#pragma unroll
+        for (int k = 0; k < PI_XCD_K; ++k) pi_xcd_request_corners(src, base[k], vp[k]);
+        pi_xcd_wait(vp);
+        float dmax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PI_XCD_K; ++k) {
+            const float e = pi_combine_corners(vp[k], fr[k]);
+            const float q = reward[k] + gamma * (kind[k] == 3u ? e : 0.0f);
+            const float nv = kind[k] >= 2u ? q : v_cur[k];
+            const float dlt = fabsf(nv - v_cur[k]);        // 0 for lanes without a state
+            dmax = dlt > dmax ? dlt : dmax;
+            v_cur[k] = nv;
+            if (kind[k] != 0u) dst[s0 + (unsigned int)k * PI_XCD_BLOCK] = nv;
+        }
+        PI_XCD_STAMP(0);
+        if (look) {
+            const float wmax = pi_wave_max(dmax);
+            if (lane == 0u) lds_red[tid >> 6] = wmax;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's values are in L2 before the workgroup says so
+        PI_XCD_STAMP(1);
+        __syncthreads();
+        PI_XCD_STAMP(2);
+        // the barrier: wave 0 publishes the workgroup's granule and polls everybody's
+        if (tid < 64u) {
+            PiGranule* bank = granules + (size_t)(j & 1) * 64u;
+            const unsigned int seq = (unsigned int)(j + 1);
+            if (lane == 0u) {
+                float m = 0.0f;
+                if (look) {
+#pragma unroll
+                    for (int wv = 0; wv < PI_XCD_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
+                }
+                bank[wg] = ((PiGranule)seq << 32) | (PiGranule)__float_as_uint(m);       // plain: stays in this XCD's L2
+            }
+            asm volatile("" ::: "memory");
+            unsigned long long t0 = 0ull;
+            unsigned int spins = 0u, bits = 0u;
+            bool ok = true;
+            while (true) {
+                PiGranule g = (PiGranule)seq << 32;
+                if (lane < W) g = __hip_atomic_load(bank + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: never this CU's L1
+                bits = (unsigned int)g;
+                if (__all((unsigned int)(g >> 32) == seq)) break;
+                if ((spins & 31u) == 31u && pi_flow_load32(status) != 0u) { ok = false; break; }
+                if (spins == 0u) t0 = wall_clock64();
+                else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
+                ++spins;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok && look) {                              // non-negative floats order like their bit patterns
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned int t = (unsigned int)__shfl_xor((int)bits, o, 64);
+                    bits = t > bits ? t : bits;
+                }
+            }
+            if (lane == 0u) {
+                if (!ok) (void)atomicMax(status, 1u);
+                if (ok && look) lds_bits = bits;
+                lds_ok = ok ? 1u : 0u;
+            }
+        }
+        PI_XCD_STAMP(3);
+        __syncthreads();
+        PI_XCD_STAMP(4);
+        if (lds_ok == 0u) { dead = true; break; }
+        done_sweeps = j + 1;
+        if (look) {
+            residual = __uint_as_float(lds_bits);
+            if (wg == 0u && tid == 0u) residual_log[slot] = residual;
+            if ((double)residual < theta) break;
+        }
+    }
+    if (dead) return;
+#if PI_XCD_TIMING
+    if ((wg == 0u || wg == W - 1u) && tid == 0u)
+        for (int k = 0; k < 5; ++k) ctl[8 + (wg == 0u ? 0 : 8) + k] = (unsigned int)(tacc[k] / (unsigned long long)done_sweeps);
+#endif
+    if (wg == 0u && tid == 0u) {
+        ctl[PI_XCD_CTL_DONE] = (unsigned int)done_sweeps;
+        ctl[PI_XCD_CTL_DONE + 1] = __float_as_uint(residual);
+    }
+}
+// Launched right behind pi_eval_xcd_kernel, ceil(n / 256) workgroups: the ONLY writer of V, *sweeps_out and *delta_out.
+// The status word decides (a wait ran out), and so does the ticket count (fewer than W workgroups ever found themselves
+// on XCD 0): *sweeps_out = -1 and V keeps the values it had before the evaluation, whatever single workgroups went
+// through; otherwise the last iterate is copied into V.
+extern "C" __global__ void __launch_bounds__(256)
+pi_xcd_finish_kernel(float* __restrict__ Va, const float* __restrict__ ring, const unsigned int* __restrict__ ctl,
+                     int* __restrict__ sweeps_out, float* __restrict__ delta_out) {
+    constexpr unsigned int N = (unsigned int)PI_GRID.n, W = PI_XCD_W;
+    unsigned int st = ctl[PI_XCD_CTL_STATUS];
+    const unsigned int done = ctl[PI_XCD_CTL_DONE];
+    if (st == 0u && (ctl[0] < W || done == 0u)) st = 1u;
+    const bool first = blockIdx.x == 0u && threadIdx.x == 0u;
+    if (st != 0u) {
+        if (first) *sweeps_out = -(int)st;
+        return;
+    }
+    const unsigned int s = blockIdx.x * 256u + threadIdx.x;
+    if (s < N) Va[s] = ring[(size_t)((done - 1u) & 1u) * PI_XCD_NPAD + s];
+    if (first) {
+        *sweeps_out = (int)done;
+        if (delta_out != nullptr) *delta_out = __uint_as_float(ctl[PI_XCD_CTL_DONE + 1]);
+    }
+}
+#endif
+
 // Launched right behind a dataflow kernel: a wave may have given up while the others went through their last barrier,
 // so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
 extern "C" __global__ void __launch_bounds__(64)

@@ -166,6 +166,9 @@ class HipSweepBackend:
                                 0 if d_changed is None else d_changed.data_ptr(), self._stream())
 
     def close(self):
+        # what the XCD-local evaluation kernel did, kept past the handle (pi_info 31 / 32): evaluations run in it, and
+        # how many of those were run again in the placement-independent kernel
+        self.xcd_evaluations, self.xcd_fallbacks = self.engine.info(31), self.engine.info(32)
         self.engine.close()
 
 

@@ -489,7 +489,11 @@ def test_small_grids_run_whole_batches_in_lds(name, shape, cuda_device):
     # launch-bound grids beyond one CU's LDS: the dataflow kernel (BASELINE config C2 is the first; 113 x 113 has a ragged
     # last workgroup; cartpole 15^4 has terminal states; the double pendulum wraps two angles)
     ("pendulum", 200, 5000, "flow"), ("mountain_car", 113, 700, "flow"), ("cartpole", 15, 1200, "flow"),
-    ("double_pendulum_swingup", 15, 777, "flow")])
+    ("double_pendulum_swingup", 15, 777, "flow"),
+    # ... and grids of up to 2^16 states on the CUs of one XCD (pi_eval_xcd_kernel; 113 x 113: a ragged last workgroup;
+    # 700 and 777 sweeps: the ring of 128 versions wraps five times)
+    ("pendulum", 200, 5000, "xcd"), ("mountain_car", 113, 700, "xcd"), ("continuous_mountain_car", 150, 400, "xcd"),
+    ("cartpole", 15, 1200, "xcd"), ("double_pendulum_swingup", 15, 777, "xcd")])
 def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel, cuda_device, monkeypatch):
     """pi_policy_evaluation runs the reference's evaluation loop (sweeps, the residual looked at on
     sweeps 0, 25, 50, ... and the last, stop below theta) in ONE launch — with V in one CU's LDS on grids that fit it,
@@ -498,14 +502,16 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
     torch = _torch()
     cfg = dict(envs.ENVS[name].CONFIG, max_eval_iter=max_eval, max_pi_iter=6)
     solvers = {}
+    monkeypatch.setenv("PI_MI355_XCD", "1" if kernel == "xcd" else "0")
     for resident in ("1", "0"):
         monkeypatch.setenv("PI_MI355_RESIDENT", resident)
         s = envs.make(name, bins, config=envs.CudaPIConfig(**cfg), device=cuda_device)
         assert s._backend.resident == (resident == "1")
         solvers[resident] = s
     a, b = solvers["1"], solvers["0"]
-    assert (a._backend.engine.info(13) > 0) == (kernel == "lds") and (a._backend.engine.info(19) > 0) == (kernel == "flow")
-    assert b._backend.engine.info(13) == 0 and b._backend.engine.info(19) == 0
+    assert (a._backend.engine.info(13) > 0) == (kernel == "lds")
+    assert (a._backend.engine.info(19) > 0) == (kernel in ("flow", "xcd")) and (a._backend.engine.info(30) > 0) == (kernel == "xcd")
+    assert b._backend.engine.info(13) == 0 and b._backend.engine.info(19) == 0 and b._backend.engine.info(30) == 0
     # one evaluation from the same start (zero V, zero policy; cartpole has terminal states)
     da, db = a.policy_evaluation(), b.policy_evaluation()
     assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"]
@@ -541,6 +547,10 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
     assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"] and a.stats["pi_iterations"] == b.stats["pi_iterations"]
     H.assert_bits_equal(a.value_function, b.value_function, "V after run()")
     assert np.array_equal(a.policy, b.policy)
+    if kernel == "xcd":
+        # every evaluation ran in the XCD-local kernel: none fell back (placement, time limit)
+        used, failed = a._backend.xcd_evaluations, a._backend.xcd_fallbacks          # kept by close()
+        assert used >= a.stats["pi_iterations"] + 2 and failed == 0, (used, failed)
 
 
 def test_small_batches_replay_as_graphs(cuda_device):
@@ -956,17 +966,19 @@ def test_memory_order_auto_picks_a_lane_dimension_from_the_dynamics(name, bins, 
     assert np.array_equal(s.policy, ref["policy"]) and s.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"])
 
 
-@pytest.mark.parametrize("name,bins", [("pendulum", 200), ("cartpole", 15), ("pendulum", 50)])
-@pytest.mark.parametrize("interval,max_sweeps", [(1, 37), (7, 60), (25, 26), (25, 1)])
-def test_one_launch_evaluation_with_any_look_interval(name, bins, interval, max_sweeps, cuda_device):
+@pytest.mark.parametrize("name,bins,xcd", [("pendulum", 200, "1"), ("pendulum", 200, "0"), ("cartpole", 15, "1"),
+                                           ("pendulum", 50, "1")])
+@pytest.mark.parametrize("interval,max_sweeps", [(1, 37), (7, 60), (25, 26), (25, 1), (50, 300)])
+def test_one_launch_evaluation_with_any_look_interval(name, bins, xcd, interval, max_sweeps, cuda_device, monkeypatch):
     """pi_policy_evaluation (dataflow kernel on the 200 x 200 and 15^4 grids, LDS-resident on 50 x 50) looks at the
     residual on sweeps 0, k, 2k, ... and the last one for ANY interval k — every sweep (k = 1: the control block holds one
     slot per look and grows with it), an interval that does not divide the limit, a single sweep — and stops at the first
     look below theta: sweeps done, every residual looked at and V equal the same schedule driven sweep by sweep."""
     torch = _torch()
+    monkeypatch.setenv("PI_MI355_XCD", xcd)
     s = envs.make(name, bins, device=cuda_device)
     eng = s._backend.engine
-    assert s._backend.resident
+    assert s._backend.resident and (eng.info(30) > 0) == (s.n_states > 12288 and xcd == "1")
     n = s.n_states
     gamma = float(np.float32(0.9))
     gen = torch.Generator(device="cpu").manual_seed(17)
@@ -1003,8 +1015,9 @@ def test_one_launch_evaluation_gives_up_loudly_instead_of_hanging(cuda_device, m
     gives up, raises the status word, every other wave leaves at its next poll, the launch ENDS, *d_sweeps = -1 and
     the solver raises — and the next evaluation with a sane limit is unaffected."""
     torch = _torch()
+    monkeypatch.setenv("PI_MI355_XCD", "0")              # the XCD-local kernel has its own fallback: the dataflow kernel is the one that gives up
     s = envs.make("pendulum", 200, device=cuda_device)
-    assert s._backend.engine.info(19) > 0
+    assert s._backend.engine.info(19) > 0 and s._backend.engine.info(30) == 0
     monkeypatch.setenv("PI_MI355_FLOW_TIMEOUT", "0.0000001")
     with pytest.raises(RuntimeError, match="gave up waiting"):
         s.policy_evaluation()

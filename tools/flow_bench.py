@@ -17,26 +17,38 @@ if len(sys.argv) > 1:
 out = []
 for name, bins in cases:
     row = {"env": name, "bins": bins}
-    for label, flag in (("one_launch", "1"), ("sweep_by_sweep", "0")):
+    for label, flag, xcd in (("xcd_local", "1", "1"), ("one_launch", "1", "0"), ("sweep_by_sweep", "0", "0")):
         os.environ["PI_MI355_RESIDENT"] = flag
+        os.environ["PI_MI355_XCD"] = xcd
         best = None
         for rep in range(3):
             s = envs.make(name, bins, device="cuda:0")
             kind = {True: "flow" if s._backend.engine.info(19) else "lds", False: "graphs"}[bool(s._backend.resident)]
+            if s._backend.engine.info(30) > 0:
+                kind = "xcd"
+            elif xcd == "1":
+                continue                                   # this grid has no XCD-local kernel: nothing to time
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             s.run()
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, s)
+        if best is None:
+            continue
         dt, s = best
         row[label] = {"path": kind, "seconds": dt, "eval_sweeps": s.stats["eval_sweeps"], "pi_iterations": s.stats["pi_iterations"],
                       "us_per_sweep": dt / s.stats["eval_sweeps"] * 1e6, "eval_seconds": s.stats["eval_seconds"],
                       "V_sha": hashlib.sha256(s.value_function.tobytes()).hexdigest()[:16],
-                      "policy_sha": hashlib.sha256(s.policy.tobytes()).hexdigest()[:16]}
+                      "policy_sha": hashlib.sha256(s.policy.tobytes()).hexdigest()[:16],
+                      "xcd_evaluations_fallbacks": [s._backend.xcd_evaluations, s._backend.xcd_fallbacks]}
     row["identical"] = (row["one_launch"]["V_sha"] == row["sweep_by_sweep"]["V_sha"]
                         and row["one_launch"]["policy_sha"] == row["sweep_by_sweep"]["policy_sha"]
                         and row["one_launch"]["eval_sweeps"] == row["sweep_by_sweep"]["eval_sweeps"])
     row["speedup"] = row["sweep_by_sweep"]["seconds"] / row["one_launch"]["seconds"]
+    if "xcd_local" in row:
+        row["identical"] = row["identical"] and all(row["xcd_local"][k] == row["sweep_by_sweep"][k]
+                                                    for k in ("V_sha", "policy_sha", "eval_sweeps"))
+        row["speedup_xcd_local"] = row["sweep_by_sweep"]["seconds"] / row["xcd_local"]["seconds"]
     print(json.dumps(row), flush=True)
     out.append(row)
