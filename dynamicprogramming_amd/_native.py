@@ -38,6 +38,8 @@ SIGNATURES = {
                                       ctypes.c_float, ctypes.c_int, _vp, _vp]),
     "pi_policy_evaluation": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_double, ctypes.c_int,
                                             ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "pi_policy_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_double, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "pi_improve_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, _vp, _vp]),
     "pi_value_sweep": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
@@ -308,6 +310,12 @@ class Engine:
         _check(lib().pi_policy_evaluation(self._h, V, policy, term, gamma, float(theta), int(max_sweeps),
                                           int(check_interval), d_sweeps, d_delta or None, d_residual_log,
                                           stream or None), "pi_policy_evaluation")
+
+    def policy_iteration(self, V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter, d_result,
+                         d_iter_log, stream=0):
+        _check(lib().pi_policy_iteration(self._h, V, policy, term, gamma, float(theta), int(max_eval_sweeps),
+                                         int(check_interval), int(max_pi_iter), d_result, d_iter_log, stream or None),
+               "pi_policy_iteration")
 
     def improve_sweep(self, V, policy, term, s_begin, s_end, gamma, d_changed=0, stream=0):
         _check(lib().pi_improve_sweep(self._h, V, policy, term, s_begin, s_end, gamma,

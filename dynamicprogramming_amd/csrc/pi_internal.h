@@ -139,11 +139,11 @@ struct pi_handle {
     // (owned).  Counters for pi_info 30-32.
     bool xcd = false, xcd_off = false;
     int xcd_states = 1024;                               // states per workgroup (PI_XCD_S)
-    int xcd_ring = 128;                                  // versions of V the kernel keeps (PI_XCD_RING)
     hipFunction_t f_xcd = nullptr, f_xcd_finish = nullptr;
     void* d_xcd = nullptr;
     size_t xcd_bytes = 0;
-    int64_t xcd_used = 0, xcd_failed = 0;
+    int64_t xcd_used = 0, xcd_failed = 0, xcd_runs = 0;
+    unsigned int* xcd_ctl = nullptr;                     // control words of the last launch (inside d_xcd)
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;
     // pi_prepare_mask: the non-terminal states of the mask at live_term, ascending (device, owned); in use only

@@ -1179,31 +1179,33 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 // ---- XCD-local evaluation: a whole policy evaluation on the CUs of ONE XCD, hand-off through that XCD's L2 -------------
 // The dataflow kernel above pays one trip through the fabric per sweep (2.8 us on MI355X) because its workgroups may
 // run anywhere.  A grid of a few ten thousand states does not need the whole chip: this kernel runs the evaluation on
-// the 32 CUs of ONE XCD (one workgroup of 1 024 threads per CU, up to 2 states per thread: 2^16 states), whose L2 all of them share, with a real
-// barrier between the Jacobi sweeps that never leaves that L2:
+// the 32 CUs of ONE XCD — one workgroup of 1 024 threads per CU, up to 2 states per thread: 2^16 states —, whose L2
+// all of them share:
 //   * successor cell, fractional offsets and reward of a thread's states stay in registers (the policy is fixed);
-//   * sweep j gathers its 2^D corners from version j - 1 of V with PLAIN loads and stores version j with PLAIN stores:
-//     a plain store stops in the XCD's L2 and a load that misses the CU's L1 is served from there;
-//   * the L1 is the one thing that could serve a stale value, so no address is read twice without an L1 invalidate in
-//     between: versions live in a ring of PI_XCD_RING buffers (memory is plentiful: 128 x 4 n bytes <= 32 MB), version j
-//     in slot j % RING, and at the start of every sweep j with j % RING == 0 every workgroup invalidates its CU's L1
-//     (buffer_inv sc1, ~1.7 us per 128 sweeps).  Between two reads of an address by one CU there is always exactly
-//     one such invalidate, and an address is never read before the barrier behind its store;
-//   * the barrier: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets, thread 0 stores the workgroup's
-//     8-byte granule {sweep number + 1, bits of the workgroup's residual maximum} with a PLAIN store (it stops in the
-//     L2), and wave 0 polls the granules of all W <= 64 workgroups — one wave-wide 8-byte load that bypasses the L1
-//     (sc1; served by the L2: four lines) — until every one carries this sweep's number: one store and one load round
-//     trip inside the XCD instead of a fabric hop.  Two banks of granules (sweep parity): a workgroup that runs ahead
-//     writes the other bank.  The residual of a look is the maximum over the granules: all workgroups stop together.
+//   * the iterates travel as data-tagged 8-byte granules {tag = sweep + 1, value bits} like the dataflow kernel's, but
+//     written with PLAIN stores (a plain store stops in the XCD's L2) and read with 16-byte loads that bypass the
+//     reader's L1 (sc1; the L2 answers): a thread asks for its 2^D corner granules of version j - 1, and asks again for
+//     the states whose corners do not all carry tag j yet.  No barrier, no flag, no drain between two sweeps: the
+//     critical path of a sweep is one store -> L2 -> load, nothing else;
+//   * versions live in a ring of 16; every 8th sweep — and every sweep the host loop looks at the residual on — ends
+//     with a real barrier (below), so a version is overwritten only when every workgroup is at least 8 sweeps past
+//     the sweep that read it;
+//   * the barrier: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets, thread 0 stores the
+//     workgroup's flag granule {sweep + 1, bits of the workgroup's residual maximum} (plain), and wave 0 polls the flag
+//     granules of all W <= 64 workgroups — one wave-wide 8-byte sc1 load, four lines — until every one carries this
+//     sweep's number.  Two banks of flags (parity of the barrier count).  The residual of a look is the maximum over
+//     the flags: all workgroups stop together.
 //     What does NOT work here, measured (profiles/r05/negative_results.txt (1)): polling with a non-temporal load — it is
 //     served by the CU's L1 once the line is there (37 of 40 workgroups spun on a stale count); a counter of atomic
 //     adds polled with returning atomics — correct, but gfx950 performs device-scope atomics on the memory side of the
-//     fabric: 3.1 us per sweep, worse than the dataflow kernel's hop.
+//     fabric: 3.1 us per sweep; a barrier of this kind after EVERY sweep with untagged values — 2.3 us per sweep, because
+//     a value another CU has just stored takes ~1 400 cycles to read even through the shared L2, and the barrier's flag
+//     pays that once more.
 // HIP promises nothing about where a workgroup runs, so nothing is assumed: the host launches spare workgroups; each reads
 // its XCC id from the hardware register; the first W that find themselves on XCD 0 take a ticket and take part, the
 // others leave at once.  Too few on XCD 0 or a wait that runs out (timeout_ticks) raise the status word: every
-// workgroup leaves, and pi_xcd_finish_kernel — the ONLY writer of V and *sweeps_out — reports *sweeps_out < 0 with V
-// untouched; the host then runs the evaluation again with the placement-independent dataflow kernel.
+// wave leaves at its next poll, and pi_xcd_finish_kernel — the ONLY writer of V and *sweeps_out — reports
+// *sweeps_out < 0 with V untouched; the host then runs the evaluation again with the placement-independent dataflow kernel.
 // Arithmetic identical to pi_eval_sweep_kernel's: same bits, residuals, sweep counts.
 #ifndef PI_XCD
 #define PI_XCD 0
@@ -1213,56 +1215,163 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 #ifndef PI_XCD_TIMING
 #define PI_XCD_TIMING 0
 #endif
-#ifndef PI_XCD_RING
-#define PI_XCD_RING 128
+#define PI_XCD_RING 16
+#define PI_XCD_SYNC 8                                     // a barrier after every 8th sweep: RING >= SYNC + 1
+#ifndef PI_XCD_FIRST_SLEEP
+#define PI_XCD_FIRST_SLEEP 8                              // x 64 cycles between a wave's store and its first look at the next version
 #endif
 #define PI_XCD_CTL_STATUS 64                              // control words (on lines of their own): 0 tickets
-#define PI_XCD_CTL_DONE 80                                // sweeps done, residual bits (written by workgroup 0 at the end)
-#define PI_XCD_CTL_GRANULES 128                            // 2 banks x 64 granules of 8 bytes (256 words)
-#define PI_XCD_CTL_WORDS (PI_XCD_CTL_GRANULES + 256)
-#define PI_XCD_NPAD (((unsigned int)PI_GRID.n + 31u) & ~31u)      // floats per version: whole 128-byte lines
-// The 2^D corner values with loads that are never served by this CU's L1 (sc1: the L2 answers), issued back to back;
-// pi_xcd_wait() is the one wait for all of them.  Written as instructions: a pair is only 4-byte aligned, which the
-// hardware loads in one global_load_dwordx2 and C++ has no atomic type for.
-__device__ __forceinline__ void pi_xcd_request_corners(const float* V, unsigned int base, PiPair (&vp)[PI_NPAIR]) {
-    constexpr int kNear = 1 << (PI_D - 2);
-#pragma unroll
-    for (int m = 0; m < kNear; ++m) {
-        int far = 0;
-#pragma unroll
-        for (int d = 0; d < PI_D - 2; ++d) far += ((m >> d) & 1) * PI_GRID.stride[d];
-        const float* p = V + (base + (unsigned int)far);
-        const float* q = p + PI_GRID.stride[PI_D - 2];
-        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(vp[m]) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(vp[m | kNear]) : "v"(q) : "memory");
-    }
-}
-template <int K>
-__device__ __forceinline__ void pi_xcd_wait(PiPair (&vp)[K][PI_NPAIR]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int m = 0; m < PI_NPAIR; ++m) asm volatile("" : "+v"(vp[k][m]));      // nothing reads a pair above the wait
-}
+#define PI_XCD_CTL_DONE 80                                // sweeps done, residual bits, iterations, stable (workgroup 0, at the end)
+#define PI_XCD_CTL_FLAGS 128                              // 2 banks x 64 flag granules of 8 bytes (256 words)
+#define PI_XCD_CTL_WORDS (PI_XCD_CTL_FLAGS + 256)
+#define PI_XCD_NPAD (((unsigned int)PI_GRID.n + 15u) & ~15u)      // granules per version: whole 128-byte lines
+typedef unsigned int PiQuad __attribute__((ext_vector_type(4)));   // two adjacent granules: {bits, tag, bits, tag}
 // One workgroup per CU (PI_XCD_PAD floats of LDS that nothing else needs see to it), PI_XCD_S states per workgroup —
 // the host's choice: n over the XCD's 32 CUs, rounded up to whole 128-byte lines — i.e. PI_XCD_K = ceil(S / 1024) states
-// per thread: every CU carries the same load and the barrier waits for nobody in particular.
+// per thread: every CU carries the same load.
 #ifndef PI_XCD_S
 #define PI_XCD_S 1024
 #endif
 #define PI_XCD_K ((PI_XCD_S + PI_XCD_BLOCK - 1) / PI_XCD_BLOCK)
 #define PI_XCD_W (((unsigned int)PI_GRID.n + PI_XCD_S - 1u) / PI_XCD_S)
 #define PI_XCD_PAD 21504                                  // 84 KB: more than half a CU's LDS
+// What every wait of the kernel needs to be bounded.
+struct PiXcdWait {
+    unsigned int* status;
+    unsigned long long timeout_ticks;
+};
+// The corner values of K cells from version `src` of V, whose granules carry tag `want`: 16-byte loads that bypass the L1
+// (two adjacent granules each), asked again for the states some of whose corners are older.  need[k]: state k asks at
+// all.  Returns false when the wave gave up (status word raised by somebody, or its own time limit: it raises the word).
+template <int K>
+__device__ __forceinline__ bool pi_xcd_gather(const PiGranule* src, unsigned int want, bool (&need)[K],
+                                              const unsigned int (&base)[K], PiPair (&vp)[K][PI_NPAIR], const PiXcdWait& w,
+                                              unsigned int& polls) {
+    constexpr int kNear = 1 << (PI_D - 2);
+    unsigned long long t0 = 0ull;
+    unsigned int spins = 0u;
+    while (true) {
+        PiQuad q[K][PI_NPAIR];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (need[k]) {
+#pragma unroll
+                for (int m = 0; m < kNear; ++m) {
+                    int far = 0;
+#pragma unroll
+                    for (int d = 0; d < PI_D - 2; ++d) far += ((m >> d) & 1) * PI_GRID.stride[d];
+                    const PiGranule* p = src + (base[k] + (unsigned int)far);
+                    const PiGranule* p2 = p + PI_GRID.stride[PI_D - 2];
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[k][m]) : "v"(p) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[k][m | kNear]) : "v"(p2) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (need[k]) {
+                bool fresh = true;
+#pragma unroll
+                for (int m = 0; m < PI_NPAIR; ++m) {
+                    asm volatile("" : "+v"(q[k][m]));                  // nothing reads a quad above the wait
+                    fresh = fresh && q[k][m].y == want && q[k][m].w == want;
+                }
+                if (fresh) {
+#pragma unroll
+                    for (int m = 0; m < PI_NPAIR; ++m) {
+                        vp[k][m].x = __uint_as_float(q[k][m].x);
+                        vp[k][m].y = __uint_as_float(q[k][m].z);
+                    }
+                    need[k] = false;
+                }
+            }
+            any = any || need[k];
+        }
+        ++polls;
+        if (!__any(any)) return true;
+        if ((spins & 31u) == 31u && pi_flow_load32(w.status) != 0u) return false;
+        if (spins == 0u) t0 = wall_clock64();
+        else if (wall_clock64() - t0 > w.timeout_ticks) {
+            if ((threadIdx.x & 63u) == 0u) (void)atomicMax(w.status, 1u);
+            return false;
+        }
+        ++spins;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// The barrier between the workgroups of the XCD, carrying one word per workgroup: every wave has drained its stores and
+// left its word (a residual maximum as float bits, or a count) in lds_part[wave]; wave 0 folds them (maximum of the bit
+// patterns, or sum), publishes the workgroup's flag granule {number of this barrier, word} with a plain store and polls
+// the flags of all W workgroups until every one carries the number.  Returns false when a wait ran out; `out`: the
+// maximum / sum over all workgroups, the same in every thread.
+template <bool SUM>
+__device__ __forceinline__ bool pi_xcd_barrier(unsigned int& barriers, unsigned int wg, unsigned int* lds_part, unsigned int* lds_word,
+                                               unsigned int* lds_ok, PiGranule* flags, const PiXcdWait& w, unsigned int& out) {
+    constexpr unsigned int W = PI_XCD_W;
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's values are in L2 before the workgroup says so
+    __syncthreads();
+    if (tid < 64u) {
+        PiGranule* bank = flags + (size_t)(barriers & 1u) * 64u;
+        const unsigned int seq = barriers + 1u;
+        if (lane == 0u) {
+            unsigned int m = 0u;
+#pragma unroll
+            for (int wv = 0; wv < PI_XCD_BLOCK / 64; ++wv) m = SUM ? m + lds_part[wv] : (lds_part[wv] > m ? lds_part[wv] : m);
+            bank[wg] = ((PiGranule)seq << 32) | (PiGranule)m;                // plain: stays in this XCD's L2
+        }
+        asm volatile("" ::: "memory");
+        unsigned long long t0 = 0ull;
+        unsigned int spins = 0u, word = 0u;
+        bool ok = true;
+        while (true) {
+            PiGranule g = (PiGranule)seq << 32;
+            if (lane < W) g = __hip_atomic_load(bank + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: never this CU's L1
+            word = (unsigned int)g;
+            if (__all((unsigned int)(g >> 32) == seq)) break;
+            if ((spins & 31u) == 31u && pi_flow_load32(w.status) != 0u) { ok = false; break; }
+            if (spins == 0u) t0 = wall_clock64();
+            else if (wall_clock64() - t0 > w.timeout_ticks) { ok = false; break; }
+            ++spins;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (ok) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned int t = (unsigned int)__shfl_xor((int)word, o, 64);
+                word = SUM ? word + t : (t > word ? t : word);
+            }
+        }
+        if (lane == 0u) {
+            if (!ok) (void)atomicMax(w.status, 1u);
+            *lds_word = word;
+            *lds_ok = ok ? 1u : 0u;
+        }
+    }
+    ++barriers;
+    __syncthreads();
+    out = *lds_word;
+    return *lds_ok != 0u;
+}
+// max_pi_iter == 0: ONE policy evaluation under the policy at `policy` (pi_policy_evaluation).  max_pi_iter >= 1: the
+// reference's whole run() (:357-370) — evaluate, improve, until no entry of the policy changes or max_pi_iter rounds are
+// done — in this one launch: the greedy step reads the evaluation's last version (tagged, behind the evaluation's last
+// barrier), a thread's actions stay in registers, the number of changed entries travels in the barrier's flags, and
+// iter_log[4 it ..] = {sweeps, residual bits, entries changed, 0} for every round.  Results go to the ring / pol_out;
+// pi_xcd_finish_kernel copies them into V / policy after a clean run.
 extern "C" __global__ void __launch_bounds__(PI_XCD_BLOCK)
-pi_eval_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
-                   const float* __restrict__ tab, float gamma, int n_sweeps, double theta, int check_interval,
-                   float* __restrict__ residual_log, float* ring, unsigned int* ctl, unsigned long long timeout_ticks) {
+pi_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy, const unsigned char* __restrict__ term,
+              const float* __restrict__ tab, float gamma, int n_sweeps, double theta, int check_interval, int max_pi_iter,
+              float* __restrict__ residual_log, unsigned int* __restrict__ iter_log, PiGranule* ring, int* __restrict__ pol_out,
+              unsigned int* ctl, unsigned long long timeout_ticks) {
     constexpr unsigned int N = (unsigned int)PI_GRID.n, W = PI_XCD_W;
-    static_assert(W <= 64u, "one wave polls the granules of all workgroups");
+    static_assert(W <= 64u, "one wave polls the flags of all workgroups");
+    static_assert(PI_XCD_RING >= PI_XCD_SYNC + 1, "a version must outlive the sweeps that may still read it");
     __shared__ float lds_tab[PI_GRID.tab_len];
-    __shared__ float lds_red[PI_XCD_BLOCK / 64];
-    __shared__ unsigned int lds_wg, lds_ok, lds_bits;
+    __shared__ unsigned int lds_part[PI_XCD_BLOCK / 64];
+    __shared__ unsigned int lds_wg, lds_ok, lds_word;
     __shared__ float lds_pad[PI_XCD_PAD];
     const unsigned int tid = threadIdx.x, lane = tid & 63u;
     if (n_sweeps < 0) {                                    // never: keeps the allocation
@@ -1280,7 +1389,7 @@ pi_eval_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy,
         }
         lds_wg = wg;
         lds_ok = 1u;
-        lds_bits = 0u;
+        lds_word = 0u;
     }
     pi_stage_table<PI_XCD_BLOCK>(tab, lds_tab);
     __syncthreads();
@@ -1288,146 +1397,213 @@ pi_eval_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy,
     if (wg == PI_FLOW_DEAD) return;                        // a spare workgroup, or one on another XCD
     const unsigned int s0 = wg * (unsigned int)PI_XCD_S + tid;
     const unsigned int s_end = min(N, (wg + 1u) * (unsigned int)PI_XCD_S);
+    const PiXcdWait wait{ctl + PI_XCD_CTL_STATUS, timeout_ticks};
+    PiGranule* flags = reinterpret_cast<PiGranule*>(ctl + PI_XCD_CTL_FLAGS);
 
-    // per state, once: 0 = no state (tail), 1 = terminal (keeps its value), 2 = done successor (no bootstrap), 3 = interpolates
-    unsigned int kind[PI_XCD_K], base[PI_XCD_K];
-    float fr[PI_XCD_K][PI_D], reward[PI_XCD_K], v_cur[PI_XCD_K];
+    // a thread's states: 0 = no state (tail), 1 = terminal (keeps its value and its entry of the policy), 2 = live
+    unsigned int role[PI_XCD_K];
+    int act[PI_XCD_K];
+    float v_cur[PI_XCD_K];
 #pragma unroll
     for (int k = 0; k < PI_XCD_K; ++k) {
         const unsigned int s = s0 + (unsigned int)k * PI_XCD_BLOCK;
-        kind[k] = 0u;
-        base[k] = 0u;
-        reward[k] = 0.0f;
+        role[k] = 0u;
+        act[k] = 0;
         v_cur[k] = 0.0f;
-#pragma unroll
-        for (int d = 0; d < PI_D; ++d) fr[k][d] = 0.0f;
         if (s < s_end) {
             v_cur[k] = Va[s];
-            kind[k] = 1u;
-            if (term == nullptr || !term[s]) {
-                float x[PI_D], ns[PI_D];
-                pi_state_coords(s, lds_tab, x);
-                bool done;
-                pi_dynamics(x, lds_tab[PI_TAB_ACT + pi_checked_action(policy[s], s)], ns, &reward[k], &done);
-                kind[k] = 2u;
-                if (!done) {
-                    pi_locate(ns, base[k], fr[k]);
-                    kind[k] = 3u;
-                }
-            }
+            act[k] = pi_checked_action(policy[s], s);
+            role[k] = (term == nullptr || !term[s]) ? 2u : 1u;
         }
-        __builtin_amdgcn_sched_barrier(0);                // one state at a time
     }
-    unsigned int* status = ctl + PI_XCD_CTL_STATUS;
-    PiGranule* granules = reinterpret_cast<PiGranule*>(ctl + PI_XCD_CTL_GRANULES);
-    int done_sweeps = 0;
+    unsigned int g = 0u, barriers = 0u, polls = 0u;       // g: sweeps done since the launch = number of the next version
+    unsigned int rounds = 0u, stable = 0u;
     float residual = 0.0f;
-    bool dead = false;                                     // workgroup-uniform
+    bool dead = false;                                     // wave-uniform inside a gather, workgroup-uniform behind a barrier
 #if PI_XCD_TIMING
     unsigned long long tacc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, tp = __builtin_readcyclecounter();
 #define PI_XCD_STAMP(k) do { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tp; tp = tn; } while (0)
 #else
 #define PI_XCD_STAMP(k)
 #endif
-    for (int j = 0; j < n_sweeps; ++j) {
-        const float* src = j == 0 ? Va : ring + (size_t)((j - 1) & 1) * PI_XCD_NPAD;
-        float* dst = ring + (size_t)(j & 1) * PI_XCD_NPAD;
-        const bool last = j == n_sweeps - 1;
-        const bool look = last || j % check_interval == 0;
-        const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
-        // states that do not interpolate read cell 0 (their `base`) and drop the result: no divergence around the loads,
-        // and the gathers of a thread's states are in flight together
-        PiPair vp[PI_XCD_K][PI_NPAIR];
-#pragma unroll
-        for (int k = 0; k < PI_XCD_K; ++k) pi_xcd_request_corners(src, base[k], vp[k]);
-        pi_xcd_wait(vp);
-        float dmax = 0.0f;
+    const int n_rounds = max_pi_iter > 0 ? max_pi_iter : 1;
+    for (int it = 0; it < n_rounds && !dead; ++it) {
+        // ---- under the current policy, once per state: 0 = no state, 1 = keeps its value, 2 = done successor (no
+        // bootstrap), 3 = interpolates; successor cell, fractional offsets, reward
+        unsigned int kind[PI_XCD_K], base[PI_XCD_K];
+        float fr[PI_XCD_K][PI_D], reward[PI_XCD_K];
 #pragma unroll
         for (int k = 0; k < PI_XCD_K; ++k) {
-            const float e = pi_combine_corners(vp[k], fr[k]);
-            const float q = reward[k] + gamma * (kind[k] == 3u ? e : 0.0f);
-            const float nv = kind[k] >= 2u ? q : v_cur[k];
-            const float dlt = fabsf(nv - v_cur[k]);        // 0 for lanes without a state
-            dmax = dlt > dmax ? dlt : dmax;
-            v_cur[k] = nv;
-            if (kind[k] != 0u) dst[s0 + (unsigned int)k * PI_XCD_BLOCK] = nv;
-        }
-        PI_XCD_STAMP(0);
-        if (look) {
-            const float wmax = pi_wave_max(dmax);
-            if (lane == 0u) lds_red[tid >> 6] = wmax;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's values are in L2 before the workgroup says so
-        PI_XCD_STAMP(1);
-        __syncthreads();
-        PI_XCD_STAMP(2);
-        // the barrier: wave 0 publishes the workgroup's granule and polls everybody's
-        if (tid < 64u) {
-            PiGranule* bank = granules + (size_t)(j & 1) * 64u;
-            const unsigned int seq = (unsigned int)(j + 1);
-            if (lane == 0u) {
-                float m = 0.0f;
-                if (look) {
+            const unsigned int s = s0 + (unsigned int)k * PI_XCD_BLOCK;
+            kind[k] = role[k] != 0u ? 1u : 0u;
+            base[k] = 0u;
+            reward[k] = 0.0f;
 #pragma unroll
-                    for (int wv = 0; wv < PI_XCD_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
-                }
-                bank[wg] = ((PiGranule)seq << 32) | (PiGranule)__float_as_uint(m);       // plain: stays in this XCD's L2
-            }
-            asm volatile("" ::: "memory");
-            unsigned long long t0 = 0ull;
-            unsigned int spins = 0u, bits = 0u;
-            bool ok = true;
-            while (true) {
-                PiGranule g = (PiGranule)seq << 32;
-                if (lane < W) g = __hip_atomic_load(bank + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: never this CU's L1
-                bits = (unsigned int)g;
-                if (__all((unsigned int)(g >> 32) == seq)) break;
-                if ((spins & 31u) == 31u && pi_flow_load32(status) != 0u) { ok = false; break; }
-                if (spins == 0u) t0 = wall_clock64();
-                else if ((spins & 15u) == 0u && wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
-                ++spins;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (ok && look) {                              // non-negative floats order like their bit patterns
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned int t = (unsigned int)__shfl_xor((int)bits, o, 64);
-                    bits = t > bits ? t : bits;
+            for (int d = 0; d < PI_D; ++d) fr[k][d] = 0.0f;
+            if (role[k] == 2u) {
+                float x[PI_D], ns[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                bool done;
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + act[k]], ns, &reward[k], &done);
+                kind[k] = 2u;
+                if (!done) {
+                    pi_locate(ns, base[k], fr[k]);
+                    kind[k] = 3u;
                 }
             }
-            if (lane == 0u) {
-                if (!ok) (void)atomicMax(status, 1u);
-                if (ok && look) lds_bits = bits;
-                lds_ok = ok ? 1u : 0u;
+            __builtin_amdgcn_sched_barrier(0);            // one state at a time
+        }
+        // ---- policy evaluation (:300-336)
+        int sweeps = 0;
+        for (int j = 0; j < n_sweeps; ++j) {
+            const bool last = j == n_sweeps - 1;
+            const bool look = last || j % check_interval == 0;
+            const int slot = j / check_interval + ((last && j % check_interval != 0) ? 1 : 0);
+            const bool sync = look || (g + 1u) % PI_XCD_SYNC == 0u;
+            PiPair vp[PI_XCD_K][PI_NPAIR];
+            if (g == 0u) {
+                // the caller's V: plain values, nobody writes them
+#pragma unroll
+                for (int k = 0; k < PI_XCD_K; ++k) pi_request_corners(Va, base[k], vp[k]);
+            } else {
+                bool need[PI_XCD_K];
+#pragma unroll
+                for (int k = 0; k < PI_XCD_K; ++k) need[k] = kind[k] == 3u;
+                __builtin_amdgcn_s_sleep(PI_XCD_FIRST_SLEEP);
+                if (!pi_xcd_gather<PI_XCD_K>(ring + (size_t)((g - 1u) % PI_XCD_RING) * PI_XCD_NPAD, g, need, base, vp, wait, polls)) {
+                    dead = true;
+                    break;
+                }
+            }
+            PI_XCD_STAMP(0);
+            PiGranule* dst = ring + (size_t)(g % PI_XCD_RING) * PI_XCD_NPAD;
+            float dmax = 0.0f;
+#pragma unroll
+            for (int k = 0; k < PI_XCD_K; ++k) {
+                // states that do not interpolate never asked for anything: their pairs are not looked at
+                float e = 0.0f;
+                if (kind[k] == 3u) e = pi_combine_corners(vp[k], fr[k]);
+                const float q = reward[k] + gamma * e;
+                const float nv = kind[k] >= 2u ? q : v_cur[k];
+                const float dlt = fabsf(nv - v_cur[k]);    // 0 for lanes without a state
+                dmax = dlt > dmax ? dlt : dmax;
+                v_cur[k] = nv;
+                if (kind[k] != 0u)                         // plain: stays in this XCD's L2
+                    dst[s0 + (unsigned int)k * PI_XCD_BLOCK] = ((PiGranule)(g + 1u) << 32) | (PiGranule)__float_as_uint(nv);
+            }
+            ++g;
+            sweeps = j + 1;
+            PI_XCD_STAMP(1);
+            if (!sync) continue;
+            if (look) {
+                const float wmax = pi_wave_max(dmax);
+                if (lane == 0u) lds_part[tid >> 6] = __float_as_uint(wmax);     // non-negative floats order like their bit patterns
+            } else if (lane == 0u) {
+                lds_part[tid >> 6] = 0u;
+            }
+            unsigned int bits;
+            if (!pi_xcd_barrier<false>(barriers, wg, lds_part, &lds_word, &lds_ok, flags, wait, bits)) {
+                dead = true;
+                break;
+            }
+            PI_XCD_STAMP(2);
+            if (look) {
+                residual = __uint_as_float(bits);
+                if (max_pi_iter == 0 && wg == 0u && tid == 0u) residual_log[slot] = residual;
+                if ((double)residual < theta) break;
             }
         }
-        PI_XCD_STAMP(3);
-        __syncthreads();
-        PI_XCD_STAMP(4);
-        if (lds_ok == 0u) { dead = true; break; }
-        done_sweeps = j + 1;
-        if (look) {
-            residual = __uint_as_float(lds_bits);
-            if (wg == 0u && tid == 0u) residual_log[slot] = residual;
-            if ((double)residual < theta) break;
+        if (dead || max_pi_iter == 0) break;
+        // ---- policy improvement (:338-355) from version g - 1: argmax_a r + gamma E[V], strict '>' from -1.0e30f in
+        // ascending action order (:262-280); terminal states keep their entry
+        unsigned int n_changed = 0u;
+        const PiGranule* vfin = ring + (size_t)((g - 1u) % PI_XCD_RING) * PI_XCD_NPAD;
+#pragma unroll
+        for (int k = 0; k < PI_XCD_K; ++k) {
+            const unsigned int s = s0 + (unsigned int)k * PI_XCD_BLOCK;
+            bool gave_up = false;
+            if (role[k] == 2u) {
+                float x[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                float best_q = -1.0e30f;
+                int best = 0;
+                for (int a = 0; a < PI_NA; ++a) {
+                    float ns[PI_D], rw;
+                    bool done;
+                    pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &rw, &done);
+                    float e = 0.0f;
+                    bool ask[1] = {!done};
+                    unsigned int cell[1] = {0u};
+                    float f[PI_D];
+#pragma unroll
+                    for (int d = 0; d < PI_D; ++d) f[d] = 0.0f;
+                    if (!done) pi_locate(ns, cell[0], f);
+                    PiPair v1[1][PI_NPAIR];
+                    if (__any(!done)) {
+                        if (!pi_xcd_gather<1>(vfin, g, ask, cell, v1, wait, polls)) { gave_up = true; break; }
+                    }
+                    if (!done) e = pi_combine_corners(v1[0], f);
+                    const float q = rw + gamma * e;
+                    if (q > best_q) { best_q = q; best = a; }
+                }
+                if (!gave_up && best != act[k]) {
+                    act[k] = best;
+                    ++n_changed;
+                }
+            }
+            if (__any(gave_up)) dead = true;
+        }
+        // (a wave that gave up still goes through the barrier below: it ends on the status word for everybody)
+        {
+            unsigned int wsum = n_changed;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wsum += (unsigned int)__shfl_xor((int)wsum, o, 64);
+            if (lane == 0u) lds_part[tid >> 6] = wsum;
+        }
+        unsigned int changed;
+        if (!pi_xcd_barrier<true>(barriers, wg, lds_part, &lds_word, &lds_ok, flags, wait, changed) || dead) {
+            dead = true;
+            break;
+        }
+        rounds = (unsigned int)(it + 1);
+        if (wg == 0u && tid == 0u) {
+            iter_log[4 * it + 0] = (unsigned int)sweeps;
+            iter_log[4 * it + 1] = __float_as_uint(residual);
+            iter_log[4 * it + 2] = changed;
+            iter_log[4 * it + 3] = 0u;
+        }
+        if (changed == 0u) {
+            stable = 1u;
+            break;
         }
     }
     if (dead) return;
+    if (max_pi_iter > 0) {
+#pragma unroll
+        for (int k = 0; k < PI_XCD_K; ++k)
+            if (role[k] != 0u) pol_out[s0 + (unsigned int)k * PI_XCD_BLOCK] = act[k];
+    }
 #if PI_XCD_TIMING
-    if ((wg == 0u || wg == W - 1u) && tid == 0u)
-        for (int k = 0; k < 5; ++k) ctl[8 + (wg == 0u ? 0 : 8) + k] = (unsigned int)(tacc[k] / (unsigned long long)done_sweeps);
+    if ((wg == 0u || wg == W - 1u) && tid == 0u) {
+        for (int k = 0; k < 3; ++k) ctl[8 + (wg == 0u ? 0 : 8) + k] = (unsigned int)(tacc[k] / (unsigned long long)g);
+        ctl[8 + (wg == 0u ? 0 : 8) + 3] = (unsigned int)((unsigned long long)polls * 1000ull / (unsigned long long)g);
+    }
 #endif
     if (wg == 0u && tid == 0u) {
-        ctl[PI_XCD_CTL_DONE] = (unsigned int)done_sweeps;
+        ctl[PI_XCD_CTL_DONE] = g;
         ctl[PI_XCD_CTL_DONE + 1] = __float_as_uint(residual);
+        ctl[PI_XCD_CTL_DONE + 2] = rounds;
+        ctl[PI_XCD_CTL_DONE + 3] = stable;
     }
 }
-// Launched right behind pi_eval_xcd_kernel, ceil(n / 256) workgroups: the ONLY writer of V, *sweeps_out and *delta_out.
-// The status word decides (a wait ran out), and so does the ticket count (fewer than W workgroups ever found themselves
-// on XCD 0): *sweeps_out = -1 and V keeps the values it had before the evaluation, whatever single workgroups went
-// through; otherwise the last iterate is copied into V.
+// Launched right behind pi_xcd_kernel, ceil(n / 256) workgroups: the ONLY writer of V, the policy, *sweeps_out and
+// *delta_out.  The status word decides (a wait ran out), and so does the ticket count (fewer than W workgroups ever
+// found themselves on XCD 0): *sweeps_out = -1 and V and the policy keep what they held before the launch, whatever single
+// workgroups went through; otherwise the last iterate (and, after a whole run, the policy) is copied out and *sweeps_out
+// = the sweeps done in all (one evaluation), or the rounds done (a whole run; sweeps_out[1] = 1 when the policy is stable).
 extern "C" __global__ void __launch_bounds__(256)
-pi_xcd_finish_kernel(float* __restrict__ Va, const float* __restrict__ ring, const unsigned int* __restrict__ ctl,
+pi_xcd_finish_kernel(float* __restrict__ Va, int* __restrict__ policy, const PiGranule* __restrict__ ring,
+                     const int* __restrict__ pol_out, const unsigned int* __restrict__ ctl, int whole_run,
                      int* __restrict__ sweeps_out, float* __restrict__ delta_out) {
     constexpr unsigned int N = (unsigned int)PI_GRID.n, W = PI_XCD_W;
     unsigned int st = ctl[PI_XCD_CTL_STATUS];
@@ -1439,9 +1615,17 @@ pi_xcd_finish_kernel(float* __restrict__ Va, const float* __restrict__ ring, con
         return;
     }
     const unsigned int s = blockIdx.x * 256u + threadIdx.x;
-    if (s < N) Va[s] = ring[(size_t)((done - 1u) & 1u) * PI_XCD_NPAD + s];
+    if (s < N) {
+        Va[s] = __uint_as_float((unsigned int)ring[(size_t)((done - 1u) % PI_XCD_RING) * PI_XCD_NPAD + s]);
+        if (whole_run) policy[s] = pol_out[s];
+    }
     if (first) {
-        *sweeps_out = (int)done;
+        if (whole_run) {
+            sweeps_out[0] = (int)ctl[PI_XCD_CTL_DONE + 2];
+            sweeps_out[1] = (int)ctl[PI_XCD_CTL_DONE + 3];
+        } else {
+            *sweeps_out = (int)done;
+        }
         if (delta_out != nullptr) *delta_out = __uint_as_float(ctl[PI_XCD_CTL_DONE + 1]);
     }
 }

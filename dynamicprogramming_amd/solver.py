@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import abc
 import logging
+import os
 import time
 from dataclasses import dataclass
 from itertools import product
@@ -138,6 +139,28 @@ class HipSweepBackend:
         n_looks = (done - 1) // check_interval + 1 + (1 if (done - 1) % check_interval else 0)
         return done, host[:n_looks].numpy()
 
+    @property
+    def whole_run(self) -> bool:
+        """True when the library runs evaluation AND improvement rounds in one launch on this grid (pi_info 30:
+        2-D grids of up to 2^16 states beyond one CU's LDS); PI_MI355_WHOLE_RUN=0 keeps the round-by-round loop."""
+        return self.resident and self.engine.info(30) > 0 and os.environ.get("PI_MI355_WHOLE_RUN", "1") != "0"
+
+    def policy_iteration(self, V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter):
+        """The whole run on the device (pi_policy_iteration).  Returns (rounds done, stable, [(sweeps, residual,
+        entries changed) per round]) — or None when the launch could not go through (placement, a bounded wait):
+        V and the policy are untouched then and the caller runs the loop itself.  One host synchronisation."""
+        torch = self.torch
+        out = torch.zeros(2 + 4 * max_pi_iter, dtype=torch.int32, device=self.device)
+        self.engine.policy_iteration(V.data_ptr(), policy.data_ptr(), self._ptr(term), gamma, theta, max_eval_sweeps,
+                                     check_interval, max_pi_iter, out.data_ptr(), out[2:].data_ptr(), self._stream())
+        host = out.cpu().numpy()
+        rounds = int(host[0])
+        if rounds < 0:
+            return None
+        log = host[2:2 + 4 * rounds].reshape(rounds, 4)
+        residuals = log[:, 1].copy().view(np.float32)
+        return rounds, bool(host[1]), [(int(log[r, 0]), float(residuals[r]), int(log[r, 2])) for r in range(rounds)]
+
     def reach_planes(self, term, s_begin, s_end, n_planes, dim=0):
         """bool[n_planes]: planes of V along `dim` the states of the range can read (any action)."""
         words = (n_planes + 31) // 32
@@ -166,9 +189,9 @@ class HipSweepBackend:
                                 0 if d_changed is None else d_changed.data_ptr(), self._stream())
 
     def close(self):
-        # what the XCD-local evaluation kernel did, kept past the handle (pi_info 31 / 32): evaluations run in it, and
-        # how many of those were run again in the placement-independent kernel
-        self.xcd_evaluations, self.xcd_fallbacks = self.engine.info(31), self.engine.info(32)
+        # what the XCD-local kernel did, kept past the handle (pi_info 31 - 33): evaluations run in it, how many of
+        # those were run again in the placement-independent kernel, whole runs launched in it
+        self.xcd_evaluations, self.xcd_fallbacks, self.xcd_runs = (self.engine.info(k) for k in (31, 32, 33))
         self.engine.close()
 
 
@@ -623,6 +646,9 @@ class _CudaPolicyIterationBase(abc.ABC):
 
     def run(self) -> None:
         """Evaluate / improve until the policy is stable or max_pi_iter is reached (:357-370)."""
+        if self._run_in_one_launch():
+            self._pull_tensors_from_gpu()
+            return
         for n in range(self.config.max_pi_iter):
             logger.info(f"-- PI Iteration {n + 1}/{self.config.max_pi_iter} --")
             self.policy_evaluation()
@@ -635,6 +661,46 @@ class _CudaPolicyIterationBase(abc.ABC):
             logger.warning(f"Policy Iteration hit max_pi_iter={self.config.max_pi_iter}.")
             self.stats["stable"] = False
         self._pull_tensors_from_gpu()
+
+    def _run_in_one_launch(self) -> bool:
+        """Launch-bound 2-D grids (BASELINE config C2): the same loop as run(), rounds and all, in ONE kernel launch
+        (pi_policy_iteration) — same sweeps per round, same V, same policy; the log lines are written afterwards.
+        Only when the loop is the reference's own: a subclass that overrides policy_evaluation / policy_improvement
+        gets its methods called round by round.  False: nothing was changed, run() goes on round by round."""
+        cfg = self.config
+        cls = type(self)
+        own = (cls.policy_evaluation is _CudaPolicyIterationBase.policy_evaluation
+               and cls.policy_improvement is _CudaPolicyIterationBase.policy_improvement)
+        if (self._comm is not None or not own or not getattr(self._backend, "whole_run", False)
+                or cfg.max_eval_iter < 1 or cfg.max_pi_iter < 1):
+            return False
+        t0 = time.perf_counter()
+        gamma = float(np.float32(cfg.gamma))
+        res = self._backend.policy_iteration(self.d_value_function, self.d_policy, self._mask_arg(), gamma, float(cfg.theta),
+                                             int(cfg.max_eval_iter), SYNC_INTERVAL, int(cfg.max_pi_iter))
+        if res is None:
+            logger.warning("one-launch run could not be placed; running round by round")
+            return False
+        rounds, stable, log = res
+        for n, (sweeps, delta, changed) in enumerate(log):
+            logger.info(f"-- PI Iteration {n + 1}/{cfg.max_pi_iter} --")
+            if delta < cfg.theta:
+                logger.success(f"  Eval converged at iter {sweeps - 1} | delta = {delta:.2e}")
+            else:
+                logger.warning(f"  Eval hit max_eval_iter={cfg.max_eval_iter} | delta = {delta:.2e}")
+            self.stats["eval_sweeps"] += sweeps
+            self.stats["sweeps_per_iter"].append(sweeps)
+            self.stats["improve_sweeps"] += 1
+            self.stats["last_changed"] = changed
+        self.stats["pi_iterations"] = rounds
+        self.stats["stable"] = stable
+        self._d_delta.fill_(log[-1][1])
+        if stable:
+            logger.success(f"Policy Iteration converged at iteration {rounds}.")
+        else:
+            logger.warning(f"Policy Iteration hit max_pi_iter={cfg.max_pi_iter}.")
+        self.stats["eval_seconds"] += time.perf_counter() - t0
+        return True
 
     # ── extensions beyond the reference API (SURVEY.md section 8f, item 4) ─────────────
     def value_iteration(self, max_iter: int | None = None) -> float:

@@ -10,6 +10,8 @@ wherever the top-2 action-value gap exceeds 1e-5 * max(1, |V|) (measured: no mis
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -490,15 +492,15 @@ def test_small_grids_run_whole_batches_in_lds(name, shape, cuda_device):
     # last workgroup; cartpole 15^4 has terminal states; the double pendulum wraps two angles)
     ("pendulum", 200, 5000, "flow"), ("mountain_car", 113, 700, "flow"), ("cartpole", 15, 1200, "flow"),
     ("double_pendulum_swingup", 15, 777, "flow"),
-    # ... and grids of up to 2^16 states on the CUs of one XCD (pi_eval_xcd_kernel; 113 x 113: a ragged last workgroup;
-    # 700 and 777 sweeps: the ring of 128 versions wraps five times)
-    ("pendulum", 200, 5000, "xcd"), ("mountain_car", 113, 700, "xcd"), ("continuous_mountain_car", 150, 400, "xcd"),
-    ("cartpole", 15, 1200, "xcd"), ("double_pendulum_swingup", 15, 777, "xcd")])
+    # ... and 2-D grids of up to 2^16 states on the CUs of one XCD (pi_xcd_kernel; 113 x 113: ragged workgroups, terminal
+    # states; the ring of 16 versions wraps many times): one evaluation per launch, and the whole run() in one launch
+    ("pendulum", 200, 5000, "xcd"), ("mountain_car", 113, 700, "xcd"), ("continuous_mountain_car", 150, 400, "xcd")])
 def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel, cuda_device, monkeypatch):
     """pi_policy_evaluation runs the reference's evaluation loop (sweeps, the residual looked at on
     sweeps 0, 25, 50, ... and the last, stop below theta) in ONE launch — with V in one CU's LDS on grids that fit it,
-    as tagged granules flowing between workgroups (pi_eval_flow_kernel) on launch-bound grids beyond: same number
-    of sweeps, same residuals, same V — and the same full run() — as the host-driven loop."""
+    as tagged granules flowing between workgroups (pi_eval_flow_kernel) on launch-bound grids beyond, on the CUs of
+    one XCD (pi_xcd_kernel) for the 2-D ones among those: same number of sweeps, same residuals, same V — and the same
+    full run(), which the XCD-local kernel does in ONE launch (pi_policy_iteration) — as the host-driven loop."""
     torch = _torch()
     cfg = dict(envs.ENVS[name].CONFIG, max_eval_iter=max_eval, max_pi_iter=6)
     solvers = {}
@@ -545,12 +547,105 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
     for s in (a, b):
         s.run()
     assert a.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"] and a.stats["pi_iterations"] == b.stats["pi_iterations"]
+    assert a.stats["stable"] == b.stats["stable"] and a.stats["eval_sweeps"] == b.stats["eval_sweeps"]
     H.assert_bits_equal(a.value_function, b.value_function, "V after run()")
     assert np.array_equal(a.policy, b.policy)
     if kernel == "xcd":
-        # every evaluation ran in the XCD-local kernel: none fell back (placement, time limit)
-        used, failed = a._backend.xcd_evaluations, a._backend.xcd_fallbacks          # kept by close()
-        assert used >= a.stats["pi_iterations"] + 2 and failed == 0, (used, failed)
+        # the run() above was ONE launch; the evaluations before it ran in the XCD-local kernel too, none fell back
+        assert (a._backend.xcd_runs, a._backend.xcd_evaluations, a._backend.xcd_fallbacks) == (1, 2, 0)
+        # ... and round by round through the same kernel (one launch per evaluation)
+        monkeypatch.setenv("PI_MI355_RESIDENT", "1")
+        monkeypatch.setenv("PI_MI355_WHOLE_RUN", "0")
+        c = envs.make(name, bins, config=envs.CudaPIConfig(**cfg), device=cuda_device)
+        c.policy_evaluation()
+        c.run()
+        assert c.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"] and c.stats["stable"] == b.stats["stable"]
+        assert (c._backend.xcd_runs, c._backend.xcd_evaluations, c._backend.xcd_fallbacks) == (0, 1 + c.stats["pi_iterations"], 0)
+        H.assert_bits_equal(c.value_function, b.value_function, "V after run(), round by round")
+        assert np.array_equal(c.policy, b.policy)
+
+
+@pytest.mark.parametrize("name,bins,rounds,max_eval,theta", [("pendulum", 200, 3, 60, 1e-4), ("mountain_car", 113, 40, 400, 1e-3),
+                                                             ("continuous_mountain_car", 150, 2, 1, 1e-4)])
+def test_whole_run_in_one_launch_through_the_c_abi(name, bins, rounds, max_eval, theta, cuda_device):
+    """pi_policy_iteration from a random V and a random policy, with limits that cut the loop short (3 rounds of at most
+    60 sweeps; one sweep per evaluation) and limits that let it converge: rounds done, the stable flag, the sweeps, last
+    residual and changed entries of every round, V and the policy equal the same loop driven call by call
+    (pi_policy_evaluation + pi_improve_sweep on a second handle whose XCD-local kernel is off)."""
+    torch = _torch()
+    s = envs.make(name, bins, device=cuda_device)
+    assert s._backend.whole_run
+    n = s.n_states
+    gamma = float(np.float32(0.97))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    term = s._mask_arg()
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32).to(cuda_device)
+    if term is not None:
+        V0[term[:n].bool()] = 0.0
+    pol0 = torch.randint(0, s.n_actions, (n,), generator=gen, dtype=torch.int32).to(cuda_device)
+    V, pol = V0.clone(), pol0.clone()
+    got = s._backend.policy_iteration(V, pol, term, gamma, theta, max_eval, 25, rounds)
+    assert got is not None
+    # the same loop, call by call
+    os.environ["PI_MI355_XCD"] = "0"
+    try:
+        ref = envs.make(name, bins, device=cuda_device)
+    finally:
+        del os.environ["PI_MI355_XCD"]
+    assert not ref._backend.whole_run
+    Vr, polr = V0.clone(), pol0.clone()
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    want, stable = [], False
+    for _ in range(rounds):
+        sweeps, looked = ref._backend.policy_evaluation(Vr, polr, term, gamma, theta, max_eval, 25)
+        ref._backend.improve_sweep(Vr, polr, term, 0, n, gamma, d_changed)
+        want.append((sweeps, float(looked[-1]), int(d_changed.item())))
+        if want[-1][2] == 0:
+            stable = True
+            break
+    assert got[0] == len(want) and got[1] == stable
+    assert [(a, np.float32(b).tobytes(), c) for a, b, c in got[2]] == [(a, np.float32(b).tobytes(), c) for a, b, c in want]
+    H.assert_bits_equal(V.cpu().numpy(), Vr.cpu().numpy(), "V after the run")
+    assert torch.equal(pol, polr)
+    for x in (s, ref):
+        x._backend.close()
+
+
+def test_whole_run_falls_back_when_it_cannot_be_placed(cuda_device, monkeypatch):
+    """Every wait of the XCD-local kernel is bounded and nothing is written before a clean end: with a time limit no
+    barrier can meet (100 ns) the one-launch run reports failure with V and the policy untouched, run() goes on round by
+    round, the evaluations fail the same way twice, the form is switched off and the dataflow kernel finishes the run —
+    with the results of the sweep-by-sweep loop."""
+    monkeypatch.setenv("PI_MI355_XCD_TIMEOUT", "0.0000001")
+    cfg = envs.CudaPIConfig(**dict(envs.ENVS["mountain_car"].CONFIG, max_pi_iter=4))
+    s = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
+    assert s._backend.whole_run
+    s.run()
+    assert (s._backend.xcd_runs, s._backend.xcd_evaluations, s._backend.xcd_fallbacks) == (1, 2, 2)
+    monkeypatch.delenv("PI_MI355_XCD_TIMEOUT")
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    plain = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
+    plain.run()
+    assert s.stats["sweeps_per_iter"] == plain.stats["sweeps_per_iter"] and s.stats["stable"] == plain.stats["stable"]
+    H.assert_bits_equal(s.value_function, plain.value_function, "V after the fallback")
+    assert np.array_equal(s.policy, plain.policy)
+
+
+def test_a_subclass_with_its_own_improvement_step_is_called_round_by_round(cuda_device):
+    """run() takes the one-launch path only when the loop is the reference's own: a plugin that overrides
+    policy_improvement (or policy_evaluation) sees its method called every round."""
+    calls = []
+
+    class Counting(envs.ENVS["pendulum"]):
+        def policy_improvement(self):
+            calls.append(len(calls))
+            return super().policy_improvement()
+
+    cfg = envs.CudaPIConfig(**dict(envs.ENVS["pendulum"].CONFIG, max_pi_iter=3))
+    s = Counting(Counting.bins_space(200), Counting.ACTIONS, cfg, device=cuda_device)
+    assert s._backend.whole_run
+    s.run()
+    assert calls == [0, 1, 2] and s._backend.xcd_runs == 0 and s._backend.xcd_evaluations == 3
 
 
 def test_small_batches_replay_as_graphs(cuda_device):
@@ -978,7 +1073,7 @@ def test_one_launch_evaluation_with_any_look_interval(name, bins, xcd, interval,
     monkeypatch.setenv("PI_MI355_XCD", xcd)
     s = envs.make(name, bins, device=cuda_device)
     eng = s._backend.engine
-    assert s._backend.resident and (eng.info(30) > 0) == (s.n_states > 12288 and xcd == "1")
+    assert s._backend.resident and (eng.info(30) > 0) == ((name, bins, xcd) == ("pendulum", 200, "1"))
     n = s.n_states
     gamma = float(np.float32(0.9))
     gen = torch.Generator(device="cpu").manual_seed(17)

@@ -17,9 +17,11 @@ if len(sys.argv) > 1:
 out = []
 for name, bins in cases:
     row = {"env": name, "bins": bins}
-    for label, flag, xcd in (("xcd_local", "1", "1"), ("one_launch", "1", "0"), ("sweep_by_sweep", "0", "0")):
+    for label, flag, xcd, whole in (("whole_run", "1", "1", "1"), ("xcd_local", "1", "1", "0"), ("one_launch", "1", "0", "0"),
+                                    ("sweep_by_sweep", "0", "0", "0")):
         os.environ["PI_MI355_RESIDENT"] = flag
         os.environ["PI_MI355_XCD"] = xcd
+        os.environ["PI_MI355_WHOLE_RUN"] = whole
         best = None
         for rep in range(3):
             s = envs.make(name, bins, device="cuda:0")
@@ -41,14 +43,15 @@ for name, bins in cases:
                       "us_per_sweep": dt / s.stats["eval_sweeps"] * 1e6, "eval_seconds": s.stats["eval_seconds"],
                       "V_sha": hashlib.sha256(s.value_function.tobytes()).hexdigest()[:16],
                       "policy_sha": hashlib.sha256(s.policy.tobytes()).hexdigest()[:16],
-                      "xcd_evaluations_fallbacks": [s._backend.xcd_evaluations, s._backend.xcd_fallbacks]}
+                      "xcd_evaluations_fallbacks_runs": [s._backend.xcd_evaluations, s._backend.xcd_fallbacks, s._backend.xcd_runs]}
     row["identical"] = (row["one_launch"]["V_sha"] == row["sweep_by_sweep"]["V_sha"]
                         and row["one_launch"]["policy_sha"] == row["sweep_by_sweep"]["policy_sha"]
                         and row["one_launch"]["eval_sweeps"] == row["sweep_by_sweep"]["eval_sweeps"])
     row["speedup"] = row["sweep_by_sweep"]["seconds"] / row["one_launch"]["seconds"]
-    if "xcd_local" in row:
-        row["identical"] = row["identical"] and all(row["xcd_local"][k] == row["sweep_by_sweep"][k]
-                                                    for k in ("V_sha", "policy_sha", "eval_sweeps"))
-        row["speedup_xcd_local"] = row["sweep_by_sweep"]["seconds"] / row["xcd_local"]["seconds"]
+    for label in ("xcd_local", "whole_run"):
+        if label in row:
+            row["identical"] = row["identical"] and all(row[label][k] == row["sweep_by_sweep"][k]
+                                                        for k in ("V_sha", "policy_sha", "eval_sweeps", "pi_iterations"))
+            row["speedup_" + label] = row["sweep_by_sweep"]["seconds"] / row[label]["seconds"]
     print(json.dumps(row), flush=True)
     out.append(row)
