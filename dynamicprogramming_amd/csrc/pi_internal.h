@@ -139,6 +139,7 @@ struct pi_handle {
     // (owned).  Counters for pi_info 30-32.
     bool xcd = false, xcd_off = false;
     int xcd_states = 1024;                               // states per workgroup (PI_XCD_S)
+    int xcd_ring = 64;                                   // granule versions of V the kernel keeps (PI_XCD_RING)
     hipFunction_t f_xcd = nullptr, f_xcd_finish = nullptr;
     void* d_xcd = nullptr;
     size_t xcd_bytes = 0;

@@ -1187,9 +1187,9 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 //     reader's L1 (sc1; the L2 answers): a thread asks for its 2^D corner granules of version j - 1, and asks again for
 //     the states whose corners do not all carry tag j yet.  No barrier, no flag, no drain between two sweeps: the
 //     critical path of a sweep is one store -> L2 -> load, nothing else;
-//   * versions live in a ring of 16; every 8th sweep — and every sweep the host loop looks at the residual on — ends
-//     with a real barrier (below), so a version is overwritten only when every workgroup is at least 8 sweeps past
-//     the sweep that read it;
+//   * versions live in a ring of 64 (memory is plentiful: 64 x 8 n bytes <= 32 MB); every 32nd sweep — and every sweep
+//     the host loop looks at the residual on, i.e. every 25th — ends with a real barrier (below), so a version is
+//     overwritten only when every workgroup is at least 32 sweeps past the sweep that read it;
 //   * the barrier: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets, thread 0 stores the
 //     workgroup's flag granule {sweep + 1, bits of the workgroup's residual maximum} (plain), and wave 0 polls the flag
 //     granules of all W <= 64 workgroups — one wave-wide 8-byte sc1 load, four lines — until every one carries this
@@ -1215,8 +1215,10 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 #ifndef PI_XCD_TIMING
 #define PI_XCD_TIMING 0
 #endif
-#define PI_XCD_RING 16
-#define PI_XCD_SYNC 8                                     // a barrier after every 8th sweep: RING >= SYNC + 1
+#ifndef PI_XCD_RING
+#define PI_XCD_RING 64
+#endif
+#define PI_XCD_SYNC (PI_XCD_RING / 2)                     // a barrier after every 32nd sweep at the latest: RING >= SYNC + 1
 #ifndef PI_XCD_FIRST_SLEEP
 #define PI_XCD_FIRST_SLEEP 8                              // x 64 cycles between a wave's store and its first look at the next version
 #endif
