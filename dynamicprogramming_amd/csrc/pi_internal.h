@@ -113,7 +113,7 @@ struct pi_handle {
     bool has_cache_dir = false;
     hipFunction_t f_eval = nullptr, f_eval_live = nullptr, f_policy_list = nullptr, f_scan_slots = nullptr, f_mask_list = nullptr, f_improve = nullptr, f_improve_live = nullptr, f_value = nullptr, f_finalize = nullptr,
                   f_reach_planes = nullptr, f_reach_units = nullptr, f_probe_step = nullptr, f_probe_interp = nullptr,
-                  f_probe_coords = nullptr, f_resident = nullptr;
+                  f_probe_coords = nullptr, f_resident = nullptr, f_run_resident = nullptr;
     int num_cu = 0;
     int block_eval = 256, block_improve = 256;   // threads per workgroup = states per chunk
     int cpw_eval = 1, cpw_improve = 1;           // chunks a workgroup sweeps

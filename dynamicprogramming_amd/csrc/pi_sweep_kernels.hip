@@ -912,6 +912,169 @@ pi_eval_resident_kernel(float* __restrict__ Va, float* __restrict__ Vb, const in
         }
     }
 }
+// The reference's whole run() (:357-370) for a grid one CU holds, in this ONE launch (pi_policy_iteration): V and the
+// policy live in LDS, every round is the evaluation loop above (second mode) followed by the greedy step — argmax_a
+// r + gamma E[V] over the LDS table, strict '>' from -1.0e30f in ascending action order (:262-280), terminal states keep
+// their entry — until no entry changes or max_pi_iter rounds are done.  A thread improves the states it evaluates, so
+// nobody else touches its entries of the policy.  iter_log[4 r ..] = {sweeps, residual bits, entries changed, 0};
+// result[0] = rounds done, result[1] = 1 when the policy is stable.  One workgroup: nothing to wait for, nothing
+// that can fail.  Arithmetic identical to pi_eval_sweep_kernel's / pi_improve_sweep_kernel's.
+extern "C" __global__ void __launch_bounds__(PI_RESIDENT_BLOCK)
+pi_run_resident_kernel(float* __restrict__ Va, int* __restrict__ policy, const unsigned char* __restrict__ term,
+                       const float* __restrict__ tab, float gamma, int n_sweeps, double theta, int check_interval,
+                       int max_pi_iter, int* __restrict__ result, unsigned int* __restrict__ iter_log) {
+    __shared__ float lds_tab[PI_GRID.tab_len];
+    __shared__ float lv[PI_GRID.n];                       // the value table
+    __shared__ int lpol[PI_GRID.n];                       // the policy
+    __shared__ float lds_red[PI_RESIDENT_BLOCK / 64 + 1];
+    __shared__ unsigned int lds_cnt[PI_RESIDENT_BLOCK / 64 + 1];
+    constexpr unsigned int N = (unsigned int)PI_GRID.n;
+    const unsigned int tid = threadIdx.x;
+    for (unsigned int i = tid; i < N; i += PI_RESIDENT_BLOCK) {
+        lv[i] = Va[i];
+        lpol[i] = pi_checked_action(policy[i], i);
+    }
+    pi_stage_table<PI_RESIDENT_BLOCK>(tab, lds_tab);
+    __syncthreads();
+    unsigned int role[PI_RESIDENT_K];                     // 0 = no state (tail), 1 = terminal, 2 = live
+    float v_cur[PI_RESIDENT_K];
+#pragma unroll
+    for (int j = 0; j < PI_RESIDENT_K; ++j) {
+        const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+        role[j] = s < N ? ((term == nullptr || !term[s]) ? 2u : 1u) : 0u;
+        v_cur[j] = s < N ? lv[s] : 0.0f;
+    }
+    int rounds = 0, stable = 0;
+    for (int it = 0; it < max_pi_iter; ++it) {
+        // ---- under the current policy, once per state: 1 = keeps its value, 2 = done successor, 3 = interpolates
+        unsigned int kind[PI_RESIDENT_K], base[PI_RESIDENT_K];
+        float fr[PI_RESIDENT_K][PI_D], reward[PI_RESIDENT_K];
+#pragma unroll
+        for (int j = 0; j < PI_RESIDENT_K; ++j) {
+            const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+            kind[j] = role[j] != 0u ? 1u : 0u;
+            base[j] = 0u;
+            reward[j] = 0.0f;
+#pragma unroll
+            for (int d = 0; d < PI_D; ++d) fr[j][d] = 0.0f;
+            if (role[j] == 2u) {
+                float x[PI_D], ns[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                bool done;
+                pi_dynamics(x, lds_tab[PI_TAB_ACT + lpol[s]], ns, &reward[j], &done);
+                kind[j] = 2u;
+                if (!done) {
+                    pi_locate(ns, base[j], fr[j]);
+                    kind[j] = 3u;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- policy evaluation (:300-336): the loop of pi_eval_resident_kernel's second mode
+        float dmax = 0.0f;
+        int sweeps = 0;
+        for (int i = 0; i < n_sweeps; ++i) {
+            float nv[PI_RESIDENT_K];
+#pragma unroll
+            for (int j = 0; j < PI_RESIDENT_K; ++j) {
+                const float e = pi_interpolate_lds(lv, base[j], fr[j]);
+                const float q = reward[j] + gamma * (kind[j] == 3u ? e : 0.0f);
+                nv[j] = kind[j] >= 2u ? q : v_cur[j];
+                if ((j + 1) % PI_RESIDENT_OVERLAP == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                              // every lane has read the old table
+            const bool look = i == n_sweeps - 1 || i % check_interval == 0;
+            if (look) dmax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PI_RESIDENT_K; ++j) {
+                const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+                if (kind[j] != 0u) lv[s] = nv[j];
+                const float dlt = fabsf(nv[j] - v_cur[j]);
+                dmax = (look & (dlt > dmax)) ? dlt : dmax;
+                v_cur[j] = nv[j];
+            }
+            sweeps = i + 1;
+            if (look) {
+                const float wmax = pi_wave_max(dmax);
+                if ((tid & 63u) == 0u) lds_red[tid >> 6] = wmax;
+                __syncthreads();
+                if (tid == 0u) {
+                    float m = 0.0f;
+#pragma unroll
+                    for (int wv = 0; wv < PI_RESIDENT_BLOCK / 64; ++wv) m = lds_red[wv] > m ? lds_red[wv] : m;
+                    lds_red[PI_RESIDENT_BLOCK / 64] = m;
+                }
+                __syncthreads();                          // also: the new table is complete
+                if ((double)lds_red[PI_RESIDENT_BLOCK / 64] < theta) break;
+            } else {
+                __syncthreads();                          // the new table is complete
+            }
+        }
+        const float residual = lds_red[PI_RESIDENT_BLOCK / 64];
+        // ---- policy improvement (:338-355) against the table the evaluation left
+        unsigned int n_changed = 0u;
+#pragma unroll 1                                          // one copy of the action loop: registers, not speed, matter here
+        for (int j = 0; j < PI_RESIDENT_K; ++j) {
+            const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+            if (s < N && (term == nullptr || !term[s])) {
+                float x[PI_D];
+                pi_state_coords(s, lds_tab, x);
+                float best_q = -1.0e30f;
+                int best = 0;
+                for (int a = 0; a < PI_NA; ++a) {
+                    float ns[PI_D], rw;
+                    bool done;
+                    pi_dynamics(x, lds_tab[PI_TAB_ACT + a], ns, &rw, &done);
+                    float e = 0.0f;
+                    if (!done) {
+                        unsigned int cell;
+                        float f[PI_D];
+                        pi_locate(ns, cell, f);
+                        e = pi_interpolate_lds(lv, cell, f);
+                    }
+                    const float q = rw + gamma * e;
+                    if (q > best_q) { best_q = q; best = a; }
+                }
+                if (best != lpol[s]) {
+                    lpol[s] = best;
+                    ++n_changed;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_changed += (unsigned int)__shfl_xor((int)n_changed, o, 64);
+        if ((tid & 63u) == 0u) lds_cnt[tid >> 6] = n_changed;
+        __syncthreads();
+        if (tid == 0u) {
+            unsigned int c = 0u;
+#pragma unroll
+            for (int wv = 0; wv < PI_RESIDENT_BLOCK / 64; ++wv) c += lds_cnt[wv];
+            lds_cnt[PI_RESIDENT_BLOCK / 64] = c;
+            iter_log[4 * it + 0] = (unsigned int)sweeps;
+            iter_log[4 * it + 1] = __float_as_uint(residual);
+            iter_log[4 * it + 2] = c;
+            iter_log[4 * it + 3] = 0u;
+        }
+        __syncthreads();
+        rounds = it + 1;
+        if (lds_cnt[PI_RESIDENT_BLOCK / 64] == 0u) {
+            stable = 1;
+            break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PI_RESIDENT_K; ++j) {
+        const unsigned int s = (unsigned int)j * PI_RESIDENT_BLOCK + tid;
+        if (role[j] != 0u) {
+            Va[s] = v_cur[j];
+            policy[s] = lpol[s];
+        }
+    }
+    if (tid == 0u) {
+        result[0] = rounds;
+        result[1] = stable;
+    }
+}
 #endif
 
 // ---- dataflow evaluation for launch-bound grids (too big for one CU's LDS, too small to fill the chip) -------

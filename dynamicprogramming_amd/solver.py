@@ -141,9 +141,10 @@ class HipSweepBackend:
 
     @property
     def whole_run(self) -> bool:
-        """True when the library runs evaluation AND improvement rounds in one launch on this grid (pi_info 30:
-        2-D grids of up to 2^16 states beyond one CU's LDS); PI_MI355_WHOLE_RUN=0 keeps the round-by-round loop."""
-        return self.resident and self.engine.info(30) > 0 and os.environ.get("PI_MI355_WHOLE_RUN", "1") != "0"
+        """True when the library runs evaluation AND improvement rounds in one launch on this grid (pi_info 34: grids
+        one CU's LDS holds, and 2-D grids of up to 2^16 states beyond those); PI_MI355_WHOLE_RUN=0 keeps the
+        round-by-round loop."""
+        return self.resident and self.engine.info(34) > 0 and os.environ.get("PI_MI355_WHOLE_RUN", "1") != "0"
 
     def policy_iteration(self, V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter):
         """The whole run on the device (pi_policy_iteration).  Returns (rounds done, stable, [(sweeps, residual,

@@ -160,9 +160,9 @@ int pi_eval_end(pi_handle* h);
  * *d_delta (nullable) the last residual looked at, d_residual_log[k] every residual looked at
  * (k-th look; at least max_sweeps / check_interval + 2 floats).  Same arithmetic, same sweep
  * count and same V as the same loop driven from the host through pi_eval_sweeps.
- * On 2-D grids of up to 2^16 states among those (pi_info 30 > 0) the evaluation first runs on the CUs of ONE XCD, with
+ * On 2-D grids of ~4 000 to 2^16 states among those (pi_info 30 > 0) the evaluation first runs on the CUs of ONE XCD, with
  * the hand-off through that XCD's L2 (pi_xcd_kernel; placement checked at run time; the call then synchronises `stream`
- * once); when that launch cannot go through V is untouched and the dataflow kernel runs the evaluation.
+ * once); when that launch cannot go through V is untouched and the LDS-resident or the dataflow kernel runs the evaluation.
  * Dataflow kernel only: every device-side wait is bounded (PI_MI355_FLOW_TIMEOUT seconds, default 2); when a
  * workgroup gives up, *d_sweeps = -1 and V is undefined — the caller must treat that as an error.
  */
@@ -172,17 +172,19 @@ int pi_policy_evaluation(pi_handle* h, float* V, const int32_t* policy, const ui
 
 /*
  * The reference's whole run() (:357-370) — policy_evaluation (:300-336), policy_improvement (:338-355), until no entry
- * of the policy changes or max_pi_iter rounds are done — in ONE launch, for 2-D grids of up to 2^16 states beyond the
- * LDS-resident kernel's (pi_info 30 > 0; BASELINE config C2, pendulum 200 x 200, is one): the kernel runs on the CUs
- * of one XCD, the iterates travel through that XCD's L2 as tagged granules, a thread keeps the actions of its states
- * in registers.  V and policy are updated in place (the last iterate, the last policy); each evaluation does up to
- * max_eval_sweeps sweeps with the residual looked at every check_interval sweeps exactly as pi_policy_evaluation does.
+ * of the policy changes or max_pi_iter rounds are done — in ONE launch (pi_info 34 > 0), for grids the LDS-resident
+ * kernel holds (pi_info 13 > 0; BASELINE config C1, pendulum 50 x 50, is one: V and the policy stay in one CU's LDS) and
+ * for 2-D grids of ~4 000 to 2^16 states (pi_info 30 > 0; BASELINE config C2, pendulum 200 x 200, is one: the
+ * kernel runs on the CUs of one XCD, the iterates travel through that XCD's L2 as tagged granules, a thread keeps the
+ * actions of its states in registers).  V and policy are updated in place (the last iterate, the last policy); each
+ * evaluation does up to max_eval_sweeps sweeps with the residual looked at every check_interval sweeps exactly as
+ * pi_policy_evaluation does.
  * d_result[0] = rounds done (>= 1), d_result[1] = 1 when the policy is stable; d_iter_log[4 r ..] = {sweeps of round r's
  * evaluation, bits of its last residual, policy entries changed by its improvement, 0} (4 * max_pi_iter words).
  * Same arithmetic, sweep counts, V and policy as the same loop driven through pi_policy_evaluation / pi_improve_sweep.
- * Every device-side wait is bounded and workgroup placement is checked, not assumed: when the launch could not go
- * through, d_result[0] < 0 and V and policy hold what they held before the call — the caller runs the loop itself.
- * Asynchronous on `stream`.  pi_info 33 = whole runs launched.
+ * XCD-local kernel: every device-side wait is bounded and workgroup placement is checked, not assumed: when the launch
+ * could not go through, d_result[0] < 0 and V and policy hold what they held before the call — the caller runs the loop
+ * itself.  Asynchronous on `stream`.  pi_info 33 = whole runs launched.
  */
 int pi_policy_iteration(pi_handle* h, float* V, int32_t* policy, const uint8_t* term, float gamma, double theta,
                         int max_eval_sweeps, int check_interval, int max_pi_iter, int32_t* d_result, uint32_t* d_iter_log,

@@ -550,6 +550,8 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
     assert a.stats["stable"] == b.stats["stable"] and a.stats["eval_sweeps"] == b.stats["eval_sweeps"]
     H.assert_bits_equal(a.value_function, b.value_function, "V after run()")
     assert np.array_equal(a.policy, b.policy)
+    if kernel == "lds":
+        assert a._backend.xcd_runs == 1                  # the run() above was ONE launch (pi_run_resident_kernel)
     if kernel == "xcd":
         # the run() above was ONE launch; the evaluations before it ran in the XCD-local kernel too, none fell back
         assert (a._backend.xcd_runs, a._backend.xcd_evaluations, a._backend.xcd_fallbacks) == (1, 2, 0)
@@ -565,16 +567,26 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
         assert np.array_equal(c.policy, b.policy)
 
 
-@pytest.mark.parametrize("name,bins,rounds,max_eval,theta", [("pendulum", 200, 3, 60, 1e-4), ("mountain_car", 113, 40, 400, 1e-3),
-                                                             ("continuous_mountain_car", 150, 2, 1, 1e-4)])
-def test_whole_run_in_one_launch_through_the_c_abi(name, bins, rounds, max_eval, theta, cuda_device):
+@pytest.mark.parametrize("name,bins,rounds,max_eval,theta,kernel", [
+    ("pendulum", 200, 3, 60, 1e-4, "xcd"), ("mountain_car", 113, 40, 400, 1e-3, "xcd"), ("continuous_mountain_car", 150, 2, 1, 1e-4, "xcd"),
+    # the bigger ones of the grids one CU holds run on the XCD too (32 CUs are faster than one beyond ~4 000 states) ...
+    ("pendulum", 80, 4, 80, 1e-4, "xcd"), ("mountain_car", 100, 40, 400, 1e-3, "xcd"),
+    # ... the smaller ones, and every grid of that size when the XCD-local kernel is switched off, in one CU
+    # (pi_run_resident_kernel): 12 states per thread, terminal states, 4-D and 6-D
+    ("pendulum", 110, 4, 80, 1e-4, "lds"), ("mountain_car", 64, 40, 400, 1e-3, "lds"), ("cartpole", 8, 5, 120, 1e-4, "lds"),
+    ("double_cartpole", 3, 3, 30, 1e-4, "lds")])
+def test_whole_run_in_one_launch_through_the_c_abi(name, bins, rounds, max_eval, theta, kernel, cuda_device, monkeypatch):
     """pi_policy_iteration from a random V and a random policy, with limits that cut the loop short (3 rounds of at most
     60 sweeps; one sweep per evaluation) and limits that let it converge: rounds done, the stable flag, the sweeps, last
     residual and changed entries of every round, V and the policy equal the same loop driven call by call
-    (pi_policy_evaluation + pi_improve_sweep on a second handle whose XCD-local kernel is off)."""
+    (pi_policy_evaluation + pi_improve_sweep on a second handle whose one-launch kernels are off) — on launch-bound 2-D
+    grids (pi_xcd_kernel) and on grids one CU's LDS holds (pi_run_resident_kernel)."""
+    if kernel == "lds":
+        monkeypatch.setenv("PI_MI355_XCD", "0")
     torch = _torch()
     s = envs.make(name, bins, device=cuda_device)
-    assert s._backend.whole_run
+    assert s._backend.whole_run and (s._backend.engine.info(30) > 0) == (kernel == "xcd")
+    assert (s._backend.engine.info(13) > 0) == (s.n_states <= {2: 12288, 4: 4096, 6: 1024}[len(s.grid_shape)])
     n = s.n_states
     gamma = float(np.float32(0.97))
     gen = torch.Generator(device="cpu").manual_seed(5)
@@ -586,20 +598,31 @@ def test_whole_run_in_one_launch_through_the_c_abi(name, bins, rounds, max_eval,
     V, pol = V0.clone(), pol0.clone()
     got = s._backend.policy_iteration(V, pol, term, gamma, theta, max_eval, 25, rounds)
     assert got is not None
-    # the same loop, call by call
-    os.environ["PI_MI355_XCD"] = "0"
-    try:
-        ref = envs.make(name, bins, device=cuda_device)
-    finally:
-        del os.environ["PI_MI355_XCD"]
-    assert not ref._backend.whole_run
+    assert s._backend.engine.info(33) == 1 and s._backend.engine.info(32) == 0
+    # the same loop, call by call, sweep batch by sweep batch
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    ref = envs.make(name, bins, device=cuda_device)
+    assert not ref._backend.resident
     Vr, polr = V0.clone(), pol0.clone()
+    scratch = torch.zeros_like(Vr)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
     d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
     want, stable = [], False
+    eng = ref._backend.engine
     for _ in range(rounds):
-        sweeps, looked = ref._backend.policy_evaluation(Vr, polr, term, gamma, theta, max_eval, 25)
+        sweeps, last = 0, None
+        for i in range(max_eval):                         # the reference's loop (:300-336), one launch per sweep
+            look = i % 25 == 0 or i == max_eval - 1
+            eng.eval_sweep(Vr.data_ptr(), scratch.data_ptr(), polr.data_ptr(), ref._backend._ptr(term), 0, n, gamma,
+                           d_delta.data_ptr() if look else 0)
+            Vr, scratch = scratch, Vr
+            sweeps = i + 1
+            if look:
+                last = float(d_delta.item())
+                if last < theta:
+                    break
         ref._backend.improve_sweep(Vr, polr, term, 0, n, gamma, d_changed)
-        want.append((sweeps, float(looked[-1]), int(d_changed.item())))
+        want.append((sweeps, last, int(d_changed.item())))
         if want[-1][2] == 0:
             stable = True
             break
