@@ -1382,12 +1382,6 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 #define PI_XCD_RING 64
 #endif
 #define PI_XCD_SYNC (PI_XCD_RING / 2)                     // a barrier after every 32nd sweep at the latest: RING >= SYNC + 1
-#ifndef PI_XCD_ADAPTIVE
-#define PI_XCD_ADAPTIVE 0
-#endif
-#ifndef PI_XCD_ADAPT_UP
-#define PI_XCD_ADAPT_UP 2u
-#endif
 #ifndef PI_XCD_FIRST_SLEEP
 #define PI_XCD_FIRST_SLEEP 8                              // x 64 cycles between a wave's store and its first look at the next version
 #endif
@@ -1588,9 +1582,6 @@ pi_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy, cons
         }
     }
     unsigned int g = 0u, barriers = 0u, polls = 0u;       // g: sweeps done since the launch = number of the next version
-#if PI_XCD_ADAPTIVE
-    unsigned int first_sleep = PI_XCD_FIRST_SLEEP;
-#endif
     unsigned int rounds = 0u, stable = 0u;
     float residual = 0.0f;
     bool dead = false;                                     // wave-uniform inside a gather, workgroup-uniform behind a barrier
@@ -1643,22 +1634,11 @@ pi_xcd_kernel(const float* __restrict__ Va, const int* __restrict__ policy, cons
                 bool need[PI_XCD_K];
 #pragma unroll
                 for (int k = 0; k < PI_XCD_K; ++k) need[k] = kind[k] == 3u;
-#if PI_XCD_ADAPTIVE
-                // the wave's own estimate of when the next version is there: a poll that fails costs the CU's vector-memory
-                // path as much as one that succeeds, waiting too long costs the wait
-                for (unsigned int i = 0u; i < first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
-                const unsigned int before = polls;
-#else
                 __builtin_amdgcn_s_sleep(PI_XCD_FIRST_SLEEP);
-#endif
                 if (!pi_xcd_gather<PI_XCD_K>(ring + (size_t)((g - 1u) % PI_XCD_RING) * PI_XCD_NPAD, g, need, base, vp, wait, polls)) {
                     dead = true;
                     break;
                 }
-#if PI_XCD_ADAPTIVE
-                if (polls - before > 1u) first_sleep = min(first_sleep + PI_XCD_ADAPT_UP, 48u);
-                else if (first_sleep > 0u) first_sleep -= 1u;
-#endif
             }
             PI_XCD_STAMP(0);
             PiGranule* dst = ring + (size_t)(g % PI_XCD_RING) * PI_XCD_NPAD;

@@ -3,7 +3,7 @@
 Builds pi_xcd_kernel with its cycle counters (PI_MI355_XCD_TIMING), runs run() of a launch-bound 2-D grid in one launch and
 prints what the library's trace (PI_MI355_XCD_TRACE) reports for the first and the last workgroup: cycles per sweep in the
 gather, in the backup + store, the barriers' share, polls per sweep x 1000.  Other knobs are taken from the environment
-(PI_MI355_XCD_FIRST_SLEEP, PI_MI355_XCD_RING, PI_MI355_XCD_ADAPTIVE).
+(PI_MI355_XCD_FIRST_SLEEP, PI_MI355_XCD_RING).
 """
 import os, sys, time
 from pathlib import Path
