@@ -49,6 +49,71 @@ def test_run_loop_equals_oracle_run(name, shape):
     assert not hasattr(s, "d_value_function")          # device arrays dropped (:379-385)
 
 
+def test_run_in_one_launch_keeps_the_books_of_the_round_by_round_loop():
+    """run() on a grid whose backend offers the whole run in one launch (pi_policy_iteration): the solver hands over
+    V, the policy and the limits, and fills stats / results from the rounds the call reports exactly as the loop
+    would have; a call that reports failure (None: V and policy untouched) is followed by the round-by-round loop; a
+    subclass with its own policy_evaluation is never handed to it.  The one-launch call is played by a twin solver
+    driven round by round (host logic only: the real kernels are compared on the GPU)."""
+    name, shape = "mountain_car", (40, 30)
+    cfg = CudaPIConfig(**{**envs.ENVS[name].CONFIG, "max_pi_iter": 12, "max_eval_iter": 600})
+    ref = _oracle_run(name, shape, cfg)
+
+    def install(solver, fail=False):
+        seen = []
+
+        def policy_iteration(V, policy, term, gamma, theta, max_eval, interval, max_pi):
+            seen.append((float(gamma), float(theta), max_eval, interval, max_pi))
+            if fail:
+                return None
+            twin = _solver(name, shape, cfg)
+            log, stable = [], False
+            for _ in range(max_pi):
+                delta = twin.policy_evaluation()
+                stable = twin.policy_improvement()
+                log.append((twin.stats["sweeps_per_iter"][-1], delta, twin.stats["last_changed"]))
+                if stable:
+                    break
+            V.copy_(twin.d_value_function)
+            policy.copy_(twin.d_policy)
+            return len(log), stable, log
+        solver._backend.whole_run = True
+        solver._backend.policy_iteration = policy_iteration
+        return seen
+
+    s = _solver(name, shape, cfg)
+    seen = install(s)
+    s.run()
+    assert seen == [(float(np.float32(cfg.gamma)), float(cfg.theta), 600, 25, 12)]
+    assert s._backend.calls == {"eval": 0, "improve": 0}            # nothing went round by round
+    assert s.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"]) and s.stats["pi_iterations"] == ref["outer_iterations"]
+    assert s.stats["eval_sweeps"] == sum(ref["sweeps_per_iter"]) and s.stats["improve_sweeps"] == ref["outer_iterations"]
+    assert s.stats["stable"] is True and s.stats["last_changed"] == 0
+    assert np.array_equal(s.policy, ref["policy"])
+    H.assert_bits_equal(s.value_function, ref["value_function"], "V")
+    assert not hasattr(s, "d_value_function")
+    # the call could not be placed: the loop runs round by round, same results
+    f = _solver(name, shape, cfg)
+    seen = install(f, fail=True)
+    f.run()
+    assert len(seen) == 1 and f._backend.calls["improve"] == ref["outer_iterations"]
+    assert f.stats["sweeps_per_iter"] == list(ref["sweeps_per_iter"]) and np.array_equal(f.policy, ref["policy"])
+    H.assert_bits_equal(f.value_function, ref["value_function"], "V after the fallback")
+    # a plugin with its own evaluation step is called round by round
+    base = H.with_checker_backend(envs.ENVS[name])
+    rounds = []
+
+    class Own(base):
+        def policy_evaluation(self):
+            rounds.append(len(rounds))
+            return super().policy_evaluation()
+
+    o = Own(H.env_bins_space(name, shape), envs.ENVS[name].ACTIONS, cfg)
+    seen = install(o)
+    o.run()
+    assert seen == [] and len(rounds) == ref["outer_iterations"] and np.array_equal(o.policy, ref["policy"])
+
+
 def test_sweeps_between_checks_follow_the_25_rule():
     """Residual looked at on sweeps 0, 25, 50, ... and on the last allowed sweep (:325)."""
     cfg = CudaPIConfig(gamma=0.99, theta=0.0, max_eval_iter=60, max_pi_iter=1)
