@@ -430,7 +430,7 @@ def measure_extra_config(label: str, env: str, bins: int, steps: int, warmup: in
         dt, fresh = best
         out["full_run"] = {"seconds": dt, "pi_iterations": fresh.stats["pi_iterations"], "eval_sweeps": fresh.stats["eval_sweeps"],
                            "stable": bool(fresh.stats["stable"]), "us_per_eval_sweep": dt / max(fresh.stats["eval_sweeps"], 1) * 1e6,
-                           "launches": int(fresh._backend.xcd_runs), "round_by_round_evaluations": int(fresh._backend.xcd_evaluations),
+                           "launches": int(fresh._backend.whole_runs), "round_by_round_evaluations": int(fresh._backend.xcd_evaluations),
                            "note": "run() from the env's initial state, best of 3; launches = 1: evaluation and improvement "
                                    "rounds in ONE kernel launch on the CUs of one XCD"}
     solver._backend.close()

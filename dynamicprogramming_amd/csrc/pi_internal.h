@@ -143,7 +143,7 @@ struct pi_handle {
     hipFunction_t f_xcd = nullptr, f_xcd_finish = nullptr;
     void* d_xcd = nullptr;
     size_t xcd_bytes = 0;
-    int64_t xcd_used = 0, xcd_failed = 0, xcd_runs = 0;
+    int64_t xcd_used = 0, xcd_failed = 0, whole_runs = 0;
     unsigned int* xcd_ctl = nullptr;                     // control words of the last launch (inside d_xcd)
     std::vector<pi::GraphEntry> graphs;
     uint64_t graph_clock = 0;

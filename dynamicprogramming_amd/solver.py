@@ -192,7 +192,7 @@ class HipSweepBackend:
     def close(self):
         # what the XCD-local kernel did, kept past the handle (pi_info 31 - 33): evaluations run in it, how many of
         # those were run again in the placement-independent kernel, whole runs launched in it
-        self.xcd_evaluations, self.xcd_fallbacks, self.xcd_runs = (self.engine.info(k) for k in (31, 32, 33))
+        self.xcd_evaluations, self.xcd_fallbacks, self.whole_runs = (self.engine.info(k) for k in (31, 32, 33))
         self.engine.close()
 
 

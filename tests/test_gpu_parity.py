@@ -551,10 +551,10 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
     H.assert_bits_equal(a.value_function, b.value_function, "V after run()")
     assert np.array_equal(a.policy, b.policy)
     if kernel == "lds":
-        assert a._backend.xcd_runs == 1                  # the run() above was ONE launch (pi_run_resident_kernel)
+        assert a._backend.whole_runs == 1                  # the run() above was ONE launch (pi_run_resident_kernel)
     if kernel == "xcd":
         # the run() above was ONE launch; the evaluations before it ran in the XCD-local kernel too, none fell back
-        assert (a._backend.xcd_runs, a._backend.xcd_evaluations, a._backend.xcd_fallbacks) == (1, 2, 0)
+        assert (a._backend.whole_runs, a._backend.xcd_evaluations, a._backend.xcd_fallbacks) == (1, 2, 0)
         # ... and round by round through the same kernel (one launch per evaluation)
         monkeypatch.setenv("PI_MI355_RESIDENT", "1")
         monkeypatch.setenv("PI_MI355_WHOLE_RUN", "0")
@@ -562,7 +562,7 @@ def test_small_grid_policy_evaluation_in_one_launch(name, bins, max_eval, kernel
         c.policy_evaluation()
         c.run()
         assert c.stats["sweeps_per_iter"] == b.stats["sweeps_per_iter"] and c.stats["stable"] == b.stats["stable"]
-        assert (c._backend.xcd_runs, c._backend.xcd_evaluations, c._backend.xcd_fallbacks) == (0, 1 + c.stats["pi_iterations"], 0)
+        assert (c._backend.whole_runs, c._backend.xcd_evaluations, c._backend.xcd_fallbacks) == (0, 1 + c.stats["pi_iterations"], 0)
         H.assert_bits_equal(c.value_function, b.value_function, "V after run(), round by round")
         assert np.array_equal(c.policy, b.policy)
 
@@ -644,7 +644,7 @@ def test_whole_run_falls_back_when_it_cannot_be_placed(cuda_device, monkeypatch)
     s = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
     assert s._backend.whole_run
     s.run()
-    assert (s._backend.xcd_runs, s._backend.xcd_evaluations, s._backend.xcd_fallbacks) == (1, 2, 2)
+    assert (s._backend.whole_runs, s._backend.xcd_evaluations, s._backend.xcd_fallbacks) == (1, 2, 2)
     monkeypatch.delenv("PI_MI355_XCD_TIMEOUT")
     monkeypatch.setenv("PI_MI355_RESIDENT", "0")
     plain = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
@@ -668,7 +668,7 @@ def test_a_subclass_with_its_own_improvement_step_is_called_round_by_round(cuda_
     s = Counting(Counting.bins_space(200), Counting.ACTIONS, cfg, device=cuda_device)
     assert s._backend.whole_run
     s.run()
-    assert calls == [0, 1, 2] and s._backend.xcd_runs == 0 and s._backend.xcd_evaluations == 3
+    assert calls == [0, 1, 2] and s._backend.whole_runs == 0 and s._backend.xcd_evaluations == 3
 
 
 def test_small_batches_replay_as_graphs(cuda_device):

@@ -43,7 +43,7 @@ for name, bins in cases:
                       "us_per_sweep": dt / s.stats["eval_sweeps"] * 1e6, "eval_seconds": s.stats["eval_seconds"],
                       "V_sha": hashlib.sha256(s.value_function.tobytes()).hexdigest()[:16],
                       "policy_sha": hashlib.sha256(s.policy.tobytes()).hexdigest()[:16],
-                      "xcd_evaluations_fallbacks_runs": [s._backend.xcd_evaluations, s._backend.xcd_fallbacks, s._backend.xcd_runs]}
+                      "xcd_evaluations_fallbacks_runs": [s._backend.xcd_evaluations, s._backend.xcd_fallbacks, s._backend.whole_runs]}
     row["identical"] = (row["one_launch"]["V_sha"] == row["sweep_by_sweep"]["V_sha"]
                         and row["one_launch"]["policy_sha"] == row["sweep_by_sweep"]["policy_sha"]
                         and row["one_launch"]["eval_sweeps"] == row["sweep_by_sweep"]["eval_sweeps"])

@@ -51,7 +51,7 @@ def soak(name, bins, reps, whole, noise):
         s.run()
         secs.append(time.perf_counter() - t0)
         digests.add(digest(s))
-        launches += s._backend.xcd_runs + s._backend.xcd_evaluations
+        launches += s._backend.whole_runs + s._backend.xcd_evaluations
         fallbacks += s._backend.xcd_fallbacks + (1 if whole and s._backend.xcd_evaluations > 0 else 0)
         evals += s.stats["pi_iterations"]
         torch.cuda.synchronize()
