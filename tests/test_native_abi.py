@@ -357,6 +357,48 @@ def test_register_budgets_of_the_baseline_kernels(tmp_path):
         assert usage["pi_eval_sweep_kernel"]["sgpr"] <= 80, (name, usage["pi_eval_sweep_kernel"])
 
 
+def test_one_launch_run_kernels_build_and_keep_their_residency_budget(tmp_path):
+    """The kernels behind pi_policy_iteration, on the ahead-of-time build of the translation units the library hands to
+    hipRTC.  pi_xcd_kernel (BASELINE config C2, pendulum 200 x 200) wants exactly ONE 1 024-thread workgroup on each
+    of an XCD's 32 CUs: its LDS footprint must be more than half of a CU's 160 KB (a second workgroup cannot join) and
+    within it, four waves per SIMD allow 128 VGPRs, nothing may spill, and 32 workgroups must cover the grid.
+    pi_run_resident_kernel (C1, pendulum 50 x 50) is one workgroup with V and the policy in LDS."""
+    import subprocess
+    import __graft_entry__ as G
+    for (name, bins, actions), kernel in ((("pendulum", 200, None), "pi_xcd_kernel"),
+                                          (("pendulum", 50, np.linspace(-2.0, 2.0, 11, dtype=np.float32)), "pi_run_resident_kernel")):
+        eng, dyn = G._engine_for(name, bins, actions)
+        text = eng.kernel_source(dyn)
+        n = eng.n_states
+        eng.close()
+        src = tmp_path / f"{name}_{bins}.hip"
+        src.write_text(text)
+        res = subprocess.run([G.HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "--genco",
+                              "-include", "hip/hip_runtime.h", "-Rpass-analysis=kernel-resource-usage", str(src),
+                              "-o", str(tmp_path / f"{name}_{bins}.hsaco")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        usage, fn = {}, None
+        for line in res.stderr.splitlines():
+            if "Function Name:" in line:
+                fn = line.split("Function Name:")[1].split()[0]
+                usage[fn] = {}
+            elif fn and " VGPRs:" in line:
+                usage[fn]["vgpr"] = int(line.split("VGPRs:")[1].split()[0])
+            elif fn and "ScratchSize" in line:
+                usage[fn]["scratch"] = int(line.split(":")[-1].split()[0])
+            elif fn and "LDS Size" in line:
+                usage[fn]["lds"] = int(line.split(":")[-1].split()[0])
+        k = usage[kernel]
+        assert k["vgpr"] <= 128 and k["scratch"] == 0, (kernel, k)
+        if kernel == "pi_xcd_kernel":
+            assert 80 * 1024 < k["lds"] <= 160 * 1024, k
+            per_wg = int([l for l in text.splitlines() if l.startswith("#define PI_XCD_S ")][0].split()[2])
+            assert per_wg % 32 == 0 and per_wg <= 2048 and -(-n // per_wg) <= 32, (n, per_wg)
+            assert "pi_xcd_finish_kernel" in usage
+        else:
+            assert 8 * n <= k["lds"] <= 160 * 1024, k                # V and the policy
+
+
 def test_p2p_transport_kernels_build_without_a_gpu_and_host_only_handles_are_refused(tmp_path):
     """csrc/pi_p2p_kernels.hip (flag hand-shake, push, mailbox reduction) compiles for gfx950 through the library's
     hipRTC path and lands in the code-object cache; a handle without a device cannot describe itself to peers."""
