@@ -76,6 +76,8 @@ SIGNATURES = {
     "pi_infer_destroy": (None, [_vp]),
     "pi_infer_set_policy": (ctypes.c_int, [_vp, _i32p, ctypes.c_int64, _f32p, ctypes.c_int]),
     "pi_infer_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "pi_plan_schedule": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_uint64)]),
     "pi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "pi_info": (ctypes.c_int64, [_vp, ctypes.c_int]),
     "pi_debug_report": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
@@ -86,7 +88,7 @@ SIGNATURES = {
     "pi_eval_end": (ctypes.c_int, [_vp]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 _load_error: Exception | None = None
 
@@ -339,6 +341,14 @@ class Engine:
     def probe_coords(self, s_begin, s_end, out, chunks_per_workgroup=1, stream=0):
         _check(lib().pi_probe_coords(self._h, s_begin, s_end, out, int(chunks_per_workgroup),
                                      stream or None), "pi_probe_coords")
+
+    def plan_schedule(self, block, first, count, total=None, chunks_per_workgroup=1):
+        """{grid_x, grid_y, period, phase, cpw} of the launch the sweeps would make (pi_plan_schedule)."""
+        out = (ctypes.c_uint64 * 6)()
+        _check(lib().pi_plan_schedule(self._h, int(block), int(first), int(count),
+                                      int(self.info(0) if total is None else total), int(chunks_per_workgroup), out),
+               "pi_plan_schedule")
+        return dict(zip(("grid_x", "grid_y", "period", "phase", "cpw"), (int(v) for v in out)))
 
     def set_option(self, what: int, value: int) -> None:
         _check(lib().pi_set_option(self._h, int(what), int(value)), "pi_set_option")

@@ -117,6 +117,10 @@ struct pi_handle {
     int num_cu = 0;
     int block_eval = 256, block_improve = 256;   // threads per workgroup = states per chunk
     int cpw_eval = 1, cpw_improve = 1;           // chunks a workgroup sweeps
+    // Strip schedule of the sweeps (pi_set_option 7, PI_MI355_STRIP): states per period — a plane of a slow memory
+    // dimension; every XCD takes its eighth of every period.  0 = the slab schedule (an XCD walks one contiguous run).
+    int64_t strip_states = 0;
+    int64_t strip_mode = -1;             // -1 the library's choice (resolve_strip), 0 off, > 0 states per period as given
     int vgpr_eval = -1, vgpr_improve = -1;
     bool cache_hit = false;
     bool debug_bounds = false;           // PI_MI355_DEBUG=1 at pi_create: checked kernels (pi_debug_report)
@@ -189,8 +193,17 @@ int finalize(pi_handle* h, float* d_delta, uint32_t* d_changed, hipStream_t st);
 bool live_usable(const pi_handle* h, const uint8_t* term, int64_t s_begin, int64_t s_end);
 void live_span(const pi_handle* h, int64_t s_begin, int64_t s_end, int64_t* first, int64_t* count);
 void live_states(const pi_handle* h, int64_t s_begin, int64_t s_end, std::vector<int32_t>& out);   // appends, ascending
+// list_total (lists the caller passes): what the list would count over the whole grid, for the strip schedule; 0 = slab
 int launch_eval_live(pi_handle* h, const float* V, float* Vnew, const int32_t* policy, int64_t first, int64_t count,
-                     float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr);
+                     float gamma, bool want_delta, hipStream_t st, const int32_t* list = nullptr, int64_t list_total = 0);
+int64_t live_list_total(const pi_handle* h, int64_t entries);
+// PiSched of pi_sweep_kernels.hip (same layout) and the planner that fills it: the launch grid (x, y)
+struct Sched {
+    int cpw;
+    unsigned int period, phase;
+};
+struct Grid2 { unsigned x, y; };
+Grid2 plan_launch(const pi_handle* h, int block, int64_t first, int64_t count, int64_t total, int cpw, Sched* sc);
 // pi_eval_push_kernel over `count` entries of `list` with their destination masks: V'(s) goes to Vnew[s] and to
 // peers[j][s] for every bit j of dest[k] (ensure_push_module builds the kernel the first time)
 int ensure_push_module(pi_handle* h);

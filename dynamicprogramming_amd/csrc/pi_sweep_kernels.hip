@@ -423,6 +423,39 @@ __device__ __forceinline__ bool pi_first_chunk(long long count, int cpw, long lo
     return chunk0 < n_chunks;
 }
 
+// The STRIP schedule (round 6).  Under the slab schedule above an XCD walks its run of groups along memory dimension 0:
+// the planes of that dimension a successor cell spans (i0 + k, i0 + k + 1) are read a whole plane's sweep apart, and on a
+// grid whose planes are megabytes (80^4: 2 MB each) the second read finds the line gone from a 4 MiB L2 that the V' stream
+// shares — V was fetched 2.9x per sweep (profiles/r05/counters_bench_c4.json).  Here the groups are cut into PERIODS of
+// `period` groups (the host picks a period = one plane of a slow memory dimension) and XCD x takes the x-th eighth — a
+// strip — of EVERY period, period after period: what it touches between the two reads of a line is an eighth of a plane.
+// The launch is two-dimensional: blockIdx.y is the period, blockIdx.x = 8 r + x the r-th workgroup of XCD x in it (the
+// dispatcher deals workgroups to the XCDs round-robin in x-then-y order and gridDim.x is a multiple of 8, so x is still the
+// XCD: tools/xcc_probe.hip) — no division.  Strip boundaries are floor((x * period + rot) / 8) with rot = 3 * period_number
+// mod 8, so that a period that is not a multiple of 8 groups gives every XCD the same work on average (250 groups per plane
+// on 80^4: strips of 31 or 32 groups, each XCD 31.25 on average) while a boundary moves by at most one group between periods;
+// gridDim.x / 8 = ceil(period / 8) workgroups per XCD and period are launched, those beyond the strip's length leave at
+// once.  `phase`: the launch's first group lies that many groups inside its period (ranges that do not start on a period
+// boundary).  Placement only: every group is taken by exactly one workgroup (tests: pi_probe_coords walks the same schedule).
+struct PiSched {
+    int cpw;                    // chunks per workgroup
+    unsigned int period;        // groups per period; 0 = the slab schedule (gridDim.y == 1)
+    unsigned int phase;
+};
+template <int BLOCK>
+__device__ __forceinline__ bool pi_first_chunk(long long count, const PiSched& sc, long long& chunk0,
+                                               long long& n_chunks) {
+    if (sc.period == 0u) return pi_first_chunk<BLOCK>(count, sc.cpw, chunk0, n_chunks);
+    n_chunks = (count + BLOCK - 1) / BLOCK;
+    const unsigned int x = blockIdx.x % PI_NXCD, r = blockIdx.x / PI_NXCD, p = blockIdx.y;
+    const unsigned int lo8 = x * sc.period + ((p * 3u) & 7u);
+    const unsigned int b0 = lo8 >> 3, b1 = (lo8 + sc.period) >> 3;
+    if (r >= b1 - b0) return false;
+    const int g = (int)(p * sc.period + b0 + r) - (int)sc.phase;             // groups < 2^31 (n < 2^31)
+    chunk0 = (long long)g * (long long)sc.cpw;
+    return g >= 0 && chunk0 < n_chunks;
+}
+
 // Bin tables and actions -> LDS.  All loads are issued before the first store.
 template <int BLOCK>
 __device__ __forceinline__ void pi_stage_table(const float* __restrict__ tab, float* lds_tab) {
@@ -516,11 +549,11 @@ extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL) __attribute__((amdgp
 pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
                      const int* __restrict__ policy, const unsigned char* __restrict__ term,
                      const float* __restrict__ tab, long long s_begin, long long s_end,
-                     float gamma, unsigned int* __restrict__ delta_bits, int cpw, int keep_terminals) {
+                     float gamma, unsigned int* __restrict__ delta_bits, PiSched sc, int keep_terminals) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk<PI_BLOCK_EVAL>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
-    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    if (!pi_first_chunk<PI_BLOCK_EVAL>(s_end - s_begin, sc, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + sc.cpw, n_chunks) - chunk0);
 
     const unsigned int tid = threadIdx.x;
     long long sb = s_begin + chunk0 * PI_BLOCK_EVAL;                     // first state of the chunk
@@ -582,11 +615,11 @@ pi_eval_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn,
 extern "C" __global__ void __launch_bounds__(PI_BLOCK_EVAL) __attribute__((amdgpu_num_sgpr(80)))
 pi_eval_live_kernel(const float* __restrict__ V, float* __restrict__ Vn, const int* __restrict__ policy,
                     const int* __restrict__ live, const float* __restrict__ tab, long long n_live, float gamma,
-                    unsigned int* __restrict__ delta_bits, int cpw) {
+                    unsigned int* __restrict__ delta_bits, PiSched sc) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk<PI_BLOCK_EVAL>(n_live, cpw, chunk0, n_chunks)) return;
-    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    if (!pi_first_chunk<PI_BLOCK_EVAL>(n_live, sc, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + sc.cpw, n_chunks) - chunk0);
     const unsigned int tid = threadIdx.x;
     const long long kb0 = chunk0 * PI_BLOCK_EVAL;                       // first list entry of the workgroup
     const bool need_old = delta_bits != nullptr;                        // launch-uniform
@@ -1872,11 +1905,11 @@ __device__ __forceinline__ void pi_improve_body(const float* __restrict__ V, flo
                                                 const float* __restrict__ tab, long long s_begin,
                                                 long long s_end, float gamma,
                                                 unsigned int* __restrict__ delta_bits,
-                                                unsigned int* __restrict__ changed, int cpw) {
+                                                unsigned int* __restrict__ changed, PiSched sc) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
-    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(s_end - s_begin, sc, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + sc.cpw, n_chunks) - chunk0);
 
     const unsigned int tid = threadIdx.x;
     long long sb = s_begin + chunk0 * PI_BLOCK_IMPROVE;
@@ -1926,8 +1959,8 @@ extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)
 pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
                         const unsigned char* __restrict__ term, const float* __restrict__ tab,
                         long long s_begin, long long s_end, float gamma,
-                        unsigned int* __restrict__ changed, int cpw) {
-    pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed, cpw);
+                        unsigned int* __restrict__ changed, PiSched sc) {
+    pi_improve_body<false>(V, nullptr, policy, term, tab, s_begin, s_end, gamma, nullptr, changed, sc);
 }
 
 // The improvement sweep over the LIVE states only (the list of pi_prepare_mask; see pi_eval_live_kernel): an
@@ -1935,11 +1968,11 @@ pi_improve_sweep_kernel(const float* __restrict__ V, int* __restrict__ policy,
 extern "C" __global__ void __launch_bounds__(PI_BLOCK_IMPROVE)
 pi_improve_live_kernel(const float* __restrict__ V, int* __restrict__ policy, const int* __restrict__ live,
                        const float* __restrict__ tab, long long n_live, float gamma,
-                       unsigned int* __restrict__ changed, int cpw) {
+                       unsigned int* __restrict__ changed, PiSched sc) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(n_live, cpw, chunk0, n_chunks)) return;
-    const int n_here = (int)(min(chunk0 + cpw, n_chunks) - chunk0);
+    if (!pi_first_chunk<PI_BLOCK_IMPROVE>(n_live, sc, chunk0, n_chunks)) return;
+    const int n_here = (int)(min(chunk0 + sc.cpw, n_chunks) - chunk0);
     const unsigned int tid = threadIdx.x;
     const long long kb0 = chunk0 * PI_BLOCK_IMPROVE;
     auto lane_of = [&](int k) {
@@ -1978,8 +2011,8 @@ pi_value_sweep_kernel(const float* __restrict__ V, float* __restrict__ Vn, int* 
                       const unsigned char* __restrict__ term, const float* __restrict__ tab,
                       long long s_begin, long long s_end, float gamma,
                       unsigned int* __restrict__ delta_bits, unsigned int* __restrict__ changed,
-                      int cpw) {
-    pi_improve_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, changed, cpw);
+                      PiSched sc) {
+    pi_improve_body<true>(V, Vn, policy, term, tab, s_begin, s_end, gamma, delta_bits, changed, sc);
 }
 
 // Fold the PI_NSLOT accumulator slots into the caller's scalars and clear them for the next
@@ -2163,11 +2196,11 @@ pi_probe_interp_kernel(const float* __restrict__ pts, int* __restrict__ idxs,
 // out[(s - s_begin) * D + d] for s in [s_begin, s_end), walked exactly like the sweeps walk it.
 extern "C" __global__ void __launch_bounds__(PI_BLOCK)
 pi_probe_coords_kernel(const float* __restrict__ tab, long long s_begin, long long s_end,
-                       float* __restrict__ out, int cpw) {
+                       float* __restrict__ out, PiSched sc) {
     __shared__ float lds_tab[PI_GRID.tab_len];
     long long chunk0, n_chunks;
-    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, cpw, chunk0, n_chunks)) return;
-    const long long chunk_end = min(chunk0 + cpw, n_chunks);
+    if (!pi_first_chunk<PI_BLOCK>(s_end - s_begin, sc, chunk0, n_chunks)) return;
+    const long long chunk_end = min(chunk0 + sc.cpw, n_chunks);
     pi_stage_table<PI_BLOCK>(tab, lds_tab);
     __syncthreads();
     for (long long chunk = chunk0; chunk < chunk_end; ++chunk) {

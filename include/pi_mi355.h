@@ -33,7 +33,7 @@ extern "C" {
 typedef struct pi_handle pi_handle;
 
 /* ABI version of this header (bumped on any signature change). */
-#define PI_MI355_ABI_VERSION 9
+#define PI_MI355_ABI_VERSION 10
 int pi_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -364,6 +364,20 @@ int pi_probe_interp(pi_handle* h, const float* pts, int32_t* idxs, float* wgts, 
                     void* stream);
 int pi_probe_coords(pi_handle* h, int64_t s_begin, int64_t s_end, float* out, int chunks_per_workgroup,
                     void* stream);
+/*
+ * The workgroup -> chunk schedule a sweep launch would use (host only, no launch; tests and tools): a launch of
+ * `block`-thread workgroups taking `chunks_per_workgroup` chunks each over `count` units (states, or entries of a state
+ * list) from unit `first`, where `total` units stand for the whole grid (n_states for a state range).
+ * out6 = {grid x, grid y, period, phase, chunks per workgroup, 0}: period == 0 is the slab schedule (grid y = 1; XCD x =
+ * workgroup index mod 8 walks the x-th contiguous eighth of the groups); otherwise the STRIP schedule (pi_set_option 7,
+ * PI_MI355_STRIP, pi_info 35): the groups are cut into periods of `period` groups — a plane of a slow memory
+ * dimension —, the launch is two-dimensional (y = period p, x = 8 r + XCD) and XCD x takes groups
+ * [floor((x period + rot) / 8), floor(((x + 1) period + rot) / 8)), rot = 3 p mod 8, of EVERY period p, so that what an
+ * XCD's L2 sees between the two sweeps that read a line of V is an eighth of a plane instead of a whole one.  Placement only: results do not depend on it.  No reference counterpart
+ * (the reference launches one thread per state in index order, src/cuda_policy_iteration.py:305-318).
+ */
+int pi_plan_schedule(pi_handle* h, int block, int64_t first, int64_t count, int64_t total, int chunks_per_workgroup,
+                     uint64_t* out6);
 
 /* ---------------------------------------------------------------------------------------------
  * Inference: the reference's CPU helper utils/barycentric.py as one batched
@@ -396,7 +410,9 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
  * (1..64), 2 = replay small evaluation batches as hipGraphs (0 | 1), 3 = run whole-grid batches of
  * small grids in the LDS-resident kernel (0 | 1), 5 = build the fused swept-first kernel of the peer-to-peer exchange
  * now (value != 0; after pi_compile; a compile check on host-only handles), 6 = keep the live-state list of
- * pi_prepare_mask even when it fills no idle lanes (0 | 1; the fused exchange of a sharded run delivers from the list sweeps), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
+ * pi_prepare_mask even when it fills no idle lanes (0 | 1; the fused exchange of a sharded run delivers from the list sweeps),
+ * 7 = STRIP SCHEDULE of the sweeps: states per period (see pi_plan_schedule; -1 = the library's choice for the grid, the
+ * default; 0 = slab schedule; PI_MI355_STRIP in the environment at pi_create sets the same), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
  * digit k (base 8) of the value is the dimension — numbered as in pi_create and in step_dynamics' arguments —
  * that is stored as memory dimension k, 0 = slowest; e.g. 03120 (octal) = order (0, 2, 1, 3).  From then on
  * EVERY flat state index of this ABI (s_begin / s_end, the entries of V, policy and the mask, the indices the
@@ -406,7 +422,7 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
  * stays useful in an XCD's L2 — the best order beats the user's by 7-11 % on the evaluation sweeps of the
  * big BASELINE grids (tools/dim_order_sweep.py).  The order-sensitive arithmetic (corner weights as products
  * over the dimensions, the fmaf chain over the corners, :580-614, :616-649) stays in the caller's dimension
- * order, so results do not depend on the memory order, bit for bit; neither do they depend on options 0-3. */
+ * order, so results do not depend on the memory order, bit for bit; neither do they depend on options 0-3 and 7. */
 int pi_set_option(pi_handle* h, int what, int64_t value);
 
 /* Introspection: 0 n_states, 1 n_actions, 2 D, 3 chunks per workgroup (evaluation), 4 VGPRs of the
@@ -414,6 +430,7 @@ int pi_set_option(pi_handle* h, int what, int64_t value);
  * served from the cache, 8 chunks per workgroup (improvement), 9 cached graphs, 10 graphs enabled,
  * 11 / 12 threads per workgroup (evaluation / improvement), 13 states per thread of the LDS-resident
  * batch kernel (0: grid too big for it), 14 that kernel enabled, 15 checked kernels (pi_debug_report),
+ * 35 states per period of the strip schedule in use (0: slab schedule),
  * 16 live states listed by pi_prepare_mask (0: no list in use), 17 entries of the per-evaluation list of
  * pi_eval_begin (0: none), 18 the memory order as set with pi_set_option 4 (octal digits, identity by default),
  * 20+d = 1 if dimension d's interpolation division runs through the proven reciprocal path. */

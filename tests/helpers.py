@@ -267,3 +267,25 @@ def check_against_step_python(name: str, nxt, rew, done, what: str) -> dict:
     e_rew = float((np.abs(rew - r_rew) / np.maximum(1.0, np.abs(r_rew)))[far].max())
     assert e_rew <= STEP_REWARD_TOL, f"{what} {name}: reward off by {e_rew:.3g} (relative)"
     return {"next": e_next, "reward": e_rew, "flags_compared": int(far.sum()), "pairs": len(far)}
+
+
+def schedule_groups(sched: dict, n_chunks: int) -> np.ndarray:
+    """Host restatement of the kernels' workgroup -> group map (pi_first_chunk in csrc/pi_sweep_kernels.hip): the group
+    every workgroup of the launch `sched` (Engine.plan_schedule) takes, in dispatch order (x fastest), -1 for a workgroup
+    that leaves at once.  Column 1 is the XCD (dispatch index mod 8)."""
+    gx, gy, T, phase, cpw = (sched[k] for k in ("grid_x", "grid_y", "period", "phase", "cpw"))
+    assert gx % 8 == 0
+    b = np.arange(gx * gy, dtype=np.int64)
+    bx, p = b % gx, b // gx
+    x, r = bx % 8, bx // 8
+    if T == 0:                                  # slab schedule: XCD x walks the x-th contiguous run of groups
+        assert gy == 1
+        g = x * (gx // 8) + r
+        valid = np.ones(len(b), dtype=bool)
+    else:                                       # strip schedule: y = period, XCD x takes its eighth of it
+        lo8 = x * T + ((p * 3) & 7)
+        b0, b1 = lo8 >> 3, (lo8 + T) >> 3
+        g = p * T + b0 + r - phase
+        valid = (r < b1 - b0) & (g >= 0)
+    valid &= g * cpw < n_chunks
+    return np.stack([np.where(valid, g, -1), b % 8], axis=1)

@@ -429,6 +429,77 @@ def test_chunks_per_workgroup_change_speed_not_results(name, shape, cuda_device)
     eng.close()
 
 
+@pytest.mark.parametrize("name,shape", [("double_pendulum_swingup", (13, 19, 17, 23)), ("cartpole", (11, 21, 19, 17)),
+                                         ("double_cartpole", (5, 4, 6, 5, 7, 8))])
+def test_the_strip_schedule_changes_placement_not_results(name, shape, cuda_device, monkeypatch):
+    """Round 6: the strip schedule (every XCD takes its eighth of every period of groups, pi_set_option 7) against the
+    slab schedule and the oracle — V', residual, policy, changed count on the whole grid and on ragged ranges that start
+    inside a period, state ranges and the live-state list alike, for periods that are and are not whole numbers of
+    groups; pi_probe_coords walks the same schedule and must write every state of the range exactly once."""
+    torch = _torch()
+    eng, acts, (lo, hi, gshape, strides), states, term, V, pol = _sweep_case(name, shape, cuda_device, seed=31)
+    n, D = len(states), len(shape)
+    chk = H.oracle_for(name)
+    gamma = float(np.float32(0.96))
+    d_V, d_pol, d_term = _dev(V, cuda_device), _dev(pol, cuda_device), _dev(term.astype(np.uint8), cuda_device)
+    d_delta = torch.zeros(1, dtype=torch.float32, device=cuda_device)
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    plane = n // shape[0]
+    used = 0
+    for a, b in ((0, n), (n // 9 + 5, n - n // 7), (plane * 2 + 256, n)):
+        o_Vn, o_delta = chk.eval_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma, a, b)
+        o_pol, o_changed = chk.improve_sweep(states, acts, pol, V, term, lo, hi, gshape, strides, gamma, a, b)
+        for period, cpw in ((plane, 1), (plane, 2), (256 * 16, 1), (256 * 37 + 100, 3), (0, 2)):
+            eng.set_option(7, period)
+            eng.set_option(0, cpw)
+            eng.set_option(1, cpw)
+            assert eng.info(35) == period
+            used += eng.plan_schedule(256, a, b - a, chunks_per_workgroup=cpw)["period"] > 0
+            d_Vn = d_V.clone()
+            eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), a, b, gamma, d_delta.data_ptr())
+            H.assert_bits_equal(d_Vn.cpu().numpy()[a:b], o_Vn[a:b], f"V' period={period} cpw={cpw} [{a},{b})")
+            assert np.array_equal(d_Vn.cpu().numpy()[:a], V[:a]) and np.array_equal(d_Vn.cpu().numpy()[b:], V[b:])
+            H.assert_bits_equal(np.float32(d_delta.item()), np.float32(o_delta), "residual")
+            d_p2 = d_pol.clone()
+            eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), a, b, gamma, d_changed.data_ptr())
+            assert np.array_equal(d_p2.cpu().numpy()[a:b], o_pol[a:b])
+            assert np.array_equal(d_p2.cpu().numpy()[:a], pol[:a]) and np.array_equal(d_p2.cpu().numpy()[b:], pol[b:])
+            assert int(d_changed.item()) == o_changed
+            out = torch.full(((b - a) * D,), float("nan"), dtype=torch.float32, device=cuda_device)
+            eng.probe_coords(a, b, out.data_ptr(), cpw)
+            H.assert_bits_equal(out.cpu().numpy().reshape(-1, D), states[a:b], "state coordinates")
+    assert used >= 5, "the strip schedule was hardly ever taken"
+    # batches of sweeps (graphs on this size; the live-state list on grids with terminal states) and the value sweep
+    eng.set_option(0, 1)
+    eng.set_option(1, 1)
+    if term.any():
+        monkeypatch.setenv("PI_MI355_LIVE_MIN", "1")
+        eng.set_option(6, 1)
+        assert eng.prepare_mask(d_term.data_ptr()) == int((~term).sum())
+    res = {}
+    for period in (0, plane, 256 * 23):
+        eng.set_option(7, period)
+        d_a, d_b = d_V.clone(), d_V.clone()
+        eng.eval_sweeps(d_a.data_ptr(), d_b.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 7, d_delta.data_ptr())
+        d_p2, d_c = d_pol.clone(), d_V.clone()
+        eng.improve_sweep(d_b.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), 0, n, gamma, d_changed.data_ptr())
+        ch = int(d_changed.item())
+        eng.value_sweep(d_b.data_ptr(), d_c.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), 0, n, gamma, d_delta.data_ptr(),
+                        d_changed.data_ptr())
+        torch.cuda.synchronize()
+        res[period] = (d_a.cpu().numpy(), d_b.cpu().numpy(), d_p2.cpu().numpy(), ch, d_c.cpu().numpy(), float(d_delta.item()))
+    for period in (plane, 256 * 23):
+        for x, y in zip(res[0], res[period]):
+            assert H.bits_equal(np.asarray(x), np.asarray(y)), f"period {period} differs from the slab schedule"
+    cur = V.copy()
+    for _ in range(7):
+        prev = cur
+        cur, _dl = chk.eval_sweep(states, acts, pol, cur, term, lo, hi, gshape, strides, gamma)
+    H.assert_bits_equal(res[plane][1], cur, "7-sweep batch under strips vs the oracle")
+    H.assert_bits_equal(res[plane][0], prev, "6th iterate under strips vs the oracle")
+    eng.close()
+
+
 @pytest.mark.parametrize("name,shape", [("pendulum", (50, 50)), ("mountain_car", (111, 110)),
                                         ("cartpole", (8, 7, 9, 8)), ("overhead_crane", (8, 8, 8, 8)),
                                         ("double_pendulum_swingup", (7, 6, 9, 5)),

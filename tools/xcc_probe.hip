@@ -19,7 +19,40 @@ __global__ void probe(int* xcc, int* cu) {
     for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(10);
 }
 
+// Two-dimensional launches (the strip schedule of the sweeps, csrc/pi_sweep_kernels.hip): with gridDim.x a multiple of 8,
+// is workgroup (bx, by) on XCD bx % 8 for every by?  1 024-thread workgroups, more of them than fit the chip at once.
+__global__ void probe2d(int* xcc) {
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcc[blockIdx.y * gridDim.x + blockIdx.x] = (int)(x & 0xf);
+    }
+    for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(10);
+}
+static void two_dimensional(int gx, int gy, int early_exit_from) {
+    int* d;
+    hipMalloc(&d, gx * gy * sizeof(int));
+    hipMemset(d, 0xff, gx * gy * sizeof(int));
+    (void)early_exit_from;
+    hipLaunchKernelGGL(probe2d, dim3(gx, gy), dim3(1024), 0, 0, d);
+    std::vector<int> x(gx * gy);
+    hipMemcpy(x.data(), d, gx * gy * sizeof(int), hipMemcpyDeviceToHost);
+    std::set<int> first_row;
+    for (int b = 0; b < 8; ++b) first_row.insert(x[b]);
+    int mismatches = 0;
+    for (int y = 0; y < gy; ++y)
+        for (int b = 0; b < gx; ++b)
+            if (x[y * gx + b] != x[b % 8]) ++mismatches;
+    printf("2-D launch %d x %d of 1024-thread workgroups: XCDs of the first 8: %zu distinct; workgroups not on the XCD of (bx %% 8, 0): %d of %d\n",
+           gx, gy, first_row.size(), mismatches, gx * gy);
+    hipFree(d);
+}
+
 int main() {
+    two_dimensional(256, 80, 0);       // the 80^4 evaluation sweep's grid
+    two_dimensional(1000, 80, 0);      // ... the improvement sweep's
+    two_dimensional(96, 625, 0);       // a 25^6 launch with a sub-plane as the period
+    two_dimensional(24, 7, 0);
     const int nb = 2048;
     int *d_x, *d_c;
     hipMalloc(&d_x, nb * sizeof(int));
