@@ -1366,7 +1366,8 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
         }
         return;
     }
-    if (kind != 0u) Va[s] = v_cur;
+    // V itself is NOT written here (round 6): a wave elsewhere may still give up, and then the caller's V has to be what
+    // it was — pi_flow_finish_kernel copies the last version out of the ring once the status word is known to be clear
     if (wg == 0u && tid == 0u) {
         *sweeps_out = done_sweeps;
         if (delta_out != nullptr) *delta_out = residual;
@@ -1829,11 +1830,22 @@ pi_xcd_finish_kernel(float* __restrict__ Va, int* __restrict__ policy, const PiG
 }
 #endif
 
-// Launched right behind a dataflow kernel: a wave may have given up while the others went through their last barrier,
-// so the status word, not workgroup 0, has the final say on whether the evaluation is valid.
-extern "C" __global__ void __launch_bounds__(64)
-pi_flow_finish_kernel(const unsigned int* __restrict__ progress, unsigned int W, int* __restrict__ sweeps_out) {
-    if (threadIdx.x == 0u && pi_flow_load32(progress + W) != 0u) *sweeps_out = -1;
+// Launched right behind a dataflow kernel, one thread per state: a wave may have given up while the others went through
+// their last barrier, so the status word, not workgroup 0, has the final say on whether the evaluation is valid — and this
+// kernel is the ONLY writer of the caller's V: status clear -> V[s] = the value of the last version in the ring (every
+// workgroup stopped on the same sweep, *sweeps_out); status raised -> *sweeps_out = -1 and V is what it was before the
+// launch, so the caller can run the same evaluation sweep by sweep (as pi_xcd_finish_kernel does for the XCD-local kernel).
+extern "C" __global__ void __launch_bounds__(256)
+pi_flow_finish_kernel(const unsigned int* __restrict__ progress, unsigned int W, int* __restrict__ sweeps_out,
+                      const PiGranule* __restrict__ ring, float* __restrict__ Va) {
+    constexpr unsigned int N = (unsigned int)PI_GRID.n;
+    if (pi_flow_load32(progress + W) != 0u) {
+        if (blockIdx.x == 0u && threadIdx.x == 0u) *sweeps_out = -1;
+        return;
+    }
+    const int done = *sweeps_out;                          // written by the kernel in front; nobody writes it on this path
+    const unsigned int s = blockIdx.x * 256u + threadIdx.x;
+    if (s < N && done >= 1) Va[s] = __uint_as_float((unsigned int)ring[(size_t)((done - 1) % PI_FLOW_RING) * N + s]);
 }
 #endif
 

@@ -84,6 +84,7 @@ class HipSweepBackend:
         t0 = time.perf_counter()
         self.engine.compile(dynamics_src)
         self.compile_seconds = time.perf_counter() - t0
+        self.one_launch_failures = 0          # dataflow-kernel evaluations that gave up (V intact, run sweep by sweep instead)
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -118,6 +119,8 @@ class HipSweepBackend:
     def resident(self) -> bool:
         """True when the library runs a whole policy evaluation (all sweeps and residual checks) of this grid in one
         launch: the LDS-resident kernel for grids one CU holds, the dataflow kernel for launch-bound grids beyond."""
+        if self.one_launch_failures >= 2 and self.engine.info(13) == 0:
+            return False                                             # the dataflow kernel keeps timing out on this box
         return (self.engine.info(13) > 0 or self.engine.info(19) > 0) and self.engine.info(14) == 1
 
     def policy_evaluation(self, V, policy, term, gamma, theta, max_sweeps, check_interval):
@@ -133,9 +136,13 @@ class HipSweepBackend:
         host = out.cpu()
         done = int(host[looks:].view(torch.int32).item())
         if done < 0:
-            raise RuntimeError("pi_policy_evaluation: a workgroup of the one-launch evaluation kernel gave up waiting for "
-                               "its peers (PI_MI355_FLOW_TIMEOUT); V is undefined — PI_MI355_FLOW=0 selects the "
-                               "sweep-by-sweep path")
+            # a workgroup of the dataflow kernel gave up waiting for its peers (they must all be resident at once: another
+            # stream or process holding CUs is enough).  V is untouched — the finish kernel is its only writer — so the
+            # caller runs this evaluation sweep by sweep; after two such launches the kernel is not tried again.
+            self.one_launch_failures += 1
+            logger.warning("pi_policy_evaluation: the one-launch evaluation kernel gave up waiting for its peers "
+                           f"(PI_MI355_FLOW_TIMEOUT); falling back to the sweep-by-sweep loop ({self.one_launch_failures} so far)")
+            return None
         n_looks = (done - 1) // check_interval + 1 + (1 if (done - 1) % check_interval else 0)
         return done, host[:n_looks].numpy()
 
@@ -305,46 +312,57 @@ class _CudaPolicyIterationBase(abc.ABC):
         (x' = x + dt x_dot) out of the second-slowest place, and then a shard's reach into its neighbours is a band of
         whole planes instead of a triangle of rows — measured with 8 logical ranks, a rank of the 80^4 grid receives
         15.6-17.6 MiB per sweep instead of 6.9-8.4 and the row-exact swept-first set is the whole shard again
-        (profiles/r04/logical_ranks_c4_w8_memory_order.json).  PI_MI355_ORDER forces an order in either case."""
+        (profiles/r04/logical_ranks_c4_w8_memory_order.json).  PI_MI355_ORDER forces an order in either case.
+
+        Round 6: a plugin nobody has tuned — a class without a MEMORY_ORDER of its own, i.e. every subclass written for
+        the reference (:113-138) — gets its order MEASURED on big single-rank grids (`_tune_memory_order`: a handful of
+        candidate orders derived from the plugin's own dynamics, each timed on the device; the decision is cached beside
+        the code objects) instead of running in the env's order; PI_MI355_ORDER=user is the opt-out, and so is
+        MEMORY_ORDER = "user" on a class whose own order has been measured to be as good as any."""
         import os
         env = os.environ.get("PI_MI355_ORDER", "").strip().lower()
         if env in ("user", "identity", "none"):
             return None
+        big = self.n_states >= self._ORDER_MIN_STATES
         if env == "auto":
-            order = self._probe_memory_order()
+            order = self._tune_memory_order()
         elif env:
             order = tuple(int(v) for v in env.split(","))
-        elif self.MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES and not self._will_shard():
+        elif isinstance(self.MEMORY_ORDER, str):                       # "user": measured, the env's own order stays
+            return None
+        elif self.MEMORY_ORDER is not None and big and not self._will_shard():
             order = tuple(self.MEMORY_ORDER)
-        elif (self.SHARDED_MEMORY_ORDER is not None and self.n_states >= self._ORDER_MIN_STATES and self._will_shard()
-              and self._shards_over_p2p()):
+        elif (self.SHARDED_MEMORY_ORDER is not None and big and self._will_shard() and self._shards_over_p2p()):
             order = tuple(self.SHARDED_MEMORY_ORDER)
+        elif self.MEMORY_ORDER is None and big and not self._will_shard() and self._runs_the_stock_allocation():
+            order = self._tune_memory_order()
         else:
             return None
         if sorted(order) != list(range(self._D)):
             raise ValueError(f"memory order {order} is not a permutation of the {self._D} dimensions")
         return None if order == tuple(range(self._D)) else order
 
-    def _probe_memory_order(self, samples: int = 192, seed: int = 0):
-        """PI_MI355_ORDER=auto — pick the LANE dimension of an env nobody has tuned, from its own dynamics.  For every
-        candidate d >= 1 the plugin is evaluated (pi_probe_step / pi_probe_interp on the device, a throw-away handle) on
-        `samples` runs of up to 64 consecutive grid points along d, everything else random: the best lane dimension is the
-        one along which a wave's successors stay together, i.e. with the smallest mean spread of the successor cell over
-        the OTHER dimensions (double cartpole: 0.9 cells with x_dot along the lanes, 5-9 with an angle or an angular
-        speed — and x_dot is what tools/dim_order_sweep.py finds, -17 % / -31 % per evaluation sweep; double pendulum:
-        16-20 cells whatever the lane dimension, the env's own last dimension stays).  Dimension 0 stays the slowest
-        (sharding) and the others keep their order.  A heuristic for the lane dimension only; measure with the tool."""
+    def _runs_the_stock_allocation(self) -> bool:
+        """A subclass that replaces _allocate_tensors_and_compile wholesale builds its own device arrays (in the env's
+        order, as the reference does): it is left alone."""
+        for klass in type(self).__mro__:
+            if "_allocate_tensors_and_compile" in vars(klass):
+                return klass is _CudaPolicyIterationBase
+        return True
+
+    def _lane_spreads(self, dev, samples: int = 192, seed: int = 0):
+        """For every candidate lane dimension d: {k: mean spread, in cells, of the successor cells of a wave (up to 64
+        consecutive grid points along d, everything else random) over dimension k} — from the plugin's own dynamics,
+        evaluated on the device through a throw-away handle (pi_probe_step / pi_probe_interp)."""
         import torch
         D, shape = self._D, [len(b) for b in self._bins]
-        dev = torch.device("cuda", torch.cuda.current_device() if self._device_arg is None
-                           else torch.device(self._device_arg).index or 0)
         eng = _native.Engine(D, self.grid_shape, self.bounds_low, self.bounds_high, self._bins, self.action_space,
                              device=dev.index)
         try:
             eng.compile(self._dynamics_cuda_src())
             rng = np.random.default_rng(seed)
             spread = {}
-            for d in range(1, D):
+            for d in range(D):
                 L = min(64, shape[d])
                 idx = np.stack([rng.integers(0, shape[k], samples) for k in range(D)], axis=1)
                 idx = np.repeat(idx[:, None, :], L, axis=1)
@@ -364,14 +382,117 @@ class _CudaPolicyIterationBase(abc.ABC):
                 torch.cuda.synchronize(dev)
                 base = d_idx[:, 0].cpu().numpy().astype(np.int64)           # lowest corner of the successor cell (env order here)
                 cell = np.stack(np.unravel_index(base, shape), axis=1).reshape(samples, L, D)
-                spread[d] = float(sum((cell[:, :, k].max(1) - cell[:, :, k].min(1)).mean() for k in range(D) if k != d))
+                spread[d] = {k: float((cell[:, :, k].max(1) - cell[:, :, k].min(1)).mean()) for k in range(D)}
         finally:
             eng.close()
-        lane = min(range(1, D), key=lambda d: (spread[d], -d))              # ties: the env's own last dimension
-        order = tuple([k for k in range(D) if k != lane] + [lane])
-        logger.info(f"memory order (auto): spread of a wave's successors over the other dimensions, by lane dimension: "
-                    f"{ {self._bin_keys[d]: round(v, 2) for d, v in spread.items()} } -> lanes along {self._bin_keys[lane]}")
-        return order
+        return spread
+
+    def _candidate_orders(self, spread):
+        """A handful of memory orders worth timing, from the spreads of `_lane_spreads`.  Lane dimension: the one along
+        which a wave's successors stay together — the smallest total spread over the OTHER dimensions (double cartpole:
+        0.9 cells with x_dot along the lanes, 5-9 with an angle or an angular speed), ties to the env's own last
+        dimension; the runner-up as well when it is within a quarter of the best.  Its PARTNER — the dimension a wave's
+        successors spread over most, the position a lane velocity moves — is tried second-fastest (double cartpole:
+        (.., x, x_dot) is worth 8-10 % over (x, .., x_dot), profiles/r04/dim_order.txt), every remaining dimension is
+        tried as the slowest, and the env's own order is always among the candidates."""
+        D = self._D
+        total = {d: sum(v for k, v in spread[d].items() if k != d) for d in range(D)}
+        ranked = sorted(range(D), key=lambda d: (total[d], -d))
+        lanes = [ranked[0]] + [d for d in ranked[1:2] if total[d] <= 1.25 * total[ranked[0]] + 1e-9]
+        out = [tuple(range(D))]
+        for lane in lanes:
+            rest = [k for k in range(D) if k != lane]
+            out.append(tuple(rest + [lane]))
+            if D < 3:
+                continue
+            partner = max(rest, key=lambda k: (spread[lane][k], k))
+            others = [k for k in rest if k != partner]
+            for slow in others:
+                out.append(tuple([slow] + [k for k in others if k != slow] + [partner, lane]))
+            if D == 4:
+                for slow in rest:
+                    out.append(tuple([slow] + [k for k in rest if k != slow] + [lane]))
+        seen, uniq = set(), []
+        for o in out:
+            if o not in seen:
+                seen.add(o)
+                uniq.append(o)
+        return uniq
+
+    def _tune_memory_order(self, sweeps: int = 3):
+        """Pick the memory order of a plugin nobody has tuned by MEASURING it: the candidates of `_candidate_orders`,
+        each compiled (hipRTC, a second or two) and timed on this grid — one warm-up and `sweeps` evaluation sweeps of a
+        random (V, policy), the fastest sweep counts.  The decision is cached beside the code objects, keyed by the
+        kernel version, the plugin's source, the grid and the action set (PI_MI355_ORDER_CACHE=0: measure again).
+        Results never depend on the order; only the sweeps' speed does."""
+        import hashlib
+        import json
+        import os
+        import torch
+        D, n = self._D, self.n_states
+        dev = torch.device("cuda", torch.cuda.current_device() if self._device_arg is None
+                           else torch.device(self._device_arg).index or 0)
+        src = self._dynamics_cuda_src()
+        key = hashlib.sha256()
+        for part in (_native.kernel_source_hash().encode(), src.encode(), np.asarray(self.action_space, np.float32).tobytes(),
+                     *[b.tobytes() for b in self._bins]):
+            key.update(part)
+            key.update(b"|")
+        cache = _native.KERNEL_CACHE / f"order_{key.hexdigest()[:24]}.json"
+        if os.environ.get("PI_MI355_ORDER_CACHE", "1") != "0" and cache.exists():
+            try:
+                rec = json.loads(cache.read_text())
+                order = tuple(int(v) for v in rec["order"])
+                if sorted(order) == list(range(D)):
+                    self._order_tuning = rec
+                    return order
+            except (OSError, ValueError, KeyError):
+                pass
+        spread = self._lane_spreads(dev)
+        cands = self._candidate_orders(spread)
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        with torch.cuda.device(dev):
+            d_V = torch.randn(n, generator=gen, dtype=torch.float32).to(dev)
+            d_Vn = torch.empty_like(d_V)
+            d_pol = torch.randint(0, self.n_actions, (n,), generator=gen, dtype=torch.int32).to(dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            gamma = float(np.float32(self.config.gamma))
+            table = []
+            for cand in cands:
+                eng = _native.Engine(D, self.grid_shape, self.bounds_low, self.bounds_high, self._bins, self.action_space,
+                                     device=dev.index, order=None if cand == tuple(range(D)) else cand)
+                try:
+                    eng.compile(src)
+                    best = float("inf")
+                    for i in range(sweeps + 1):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), 0, 0, n, gamma, 0, st)
+                        e1.record()
+                        e1.synchronize()
+                        if i:
+                            best = min(best, e0.elapsed_time(e1))
+                finally:
+                    eng.close()
+                table.append({"order": list(cand), "eval_ms": best})
+            del d_V, d_Vn, d_pol
+        # the env's own order (first candidate) stays unless another one is at least 2 % faster
+        pick = min(table, key=lambda r: r["eval_ms"])
+        if pick["eval_ms"] > 0.98 * table[0]["eval_ms"]:
+            pick = table[0]
+        rec = {"order": pick["order"], "dims": self._bin_keys, "candidates": table,
+               "lane_spread": {self._bin_keys[d]: round(sum(v for k, v in spread[d].items() if k != d), 3) for d in spread}}
+        self._order_tuning = rec
+        logger.info("memory order (measured): " + ", ".join(f"{tuple(r['order'])} {r['eval_ms']:.3f} ms" for r in table)
+                    + f" -> {tuple(pick['order'])}")
+        try:
+            cache.parent.mkdir(parents=True, exist_ok=True)
+            tmp = cache.with_suffix(f".tmp{os.getpid()}")
+            tmp.write_text(json.dumps(rec))
+            os.replace(tmp, cache)
+        except OSError:
+            pass
+        return tuple(pick["order"])
 
     def _to_memory(self, a):
         """Whole-grid array in the user's order -> the device's memory order (identity without MEMORY_ORDER)."""
@@ -579,7 +700,10 @@ class _CudaPolicyIterationBase(abc.ABC):
         delta = float("inf")
         t0 = time.perf_counter()
         if self._comm is None and getattr(self._backend, "resident", False) and cfg.max_eval_iter >= 1:
-            return self._policy_evaluation_resident(gamma, t0)
+            delta = self._policy_evaluation_resident(gamma, t0)
+            if delta is not None:
+                return delta
+            delta = float("inf")                                     # the launch gave up with V intact: the loop below
         i = 0
         sweeps = 0
         # the policy is fixed for the whole loop: the library may drop the states whose successor is terminal
@@ -615,9 +739,11 @@ class _CudaPolicyIterationBase(abc.ABC):
         """Small grids: the same loop, run by ONE kernel launch with V in LDS (same sweeps, same
         residuals, same V); the log lines are written afterwards from the residuals it recorded."""
         cfg = self.config
-        sweeps, looked = self._backend.policy_evaluation(self.d_value_function, self.d_policy,
-                                                         self._mask_arg(), gamma, float(cfg.theta),
-                                                         int(cfg.max_eval_iter), SYNC_INTERVAL)
+        res = self._backend.policy_evaluation(self.d_value_function, self.d_policy, self._mask_arg(), gamma,
+                                              float(cfg.theta), int(cfg.max_eval_iter), SYNC_INTERVAL)
+        if res is None:
+            return None
+        sweeps, looked = res
         delta = float(looked[-1])
         for k, r in enumerate(looked):
             check = min(k * SYNC_INTERVAL, cfg.max_eval_iter - 1)

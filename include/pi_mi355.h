@@ -163,8 +163,10 @@ int pi_eval_end(pi_handle* h);
  * On 2-D grids of ~4 000 to 2^16 states among those (pi_info 30 > 0) the evaluation first runs on the CUs of ONE XCD, with
  * the hand-off through that XCD's L2 (pi_xcd_kernel; placement checked at run time; the call then synchronises `stream`
  * once); when that launch cannot go through V is untouched and the LDS-resident or the dataflow kernel runs the evaluation.
- * Dataflow kernel only: every device-side wait is bounded (PI_MI355_FLOW_TIMEOUT seconds, default 2); when a
- * workgroup gives up, *d_sweeps = -1 and V is undefined — the caller must treat that as an error.
+ * Dataflow kernel: every device-side wait is bounded (PI_MI355_FLOW_TIMEOUT seconds, default 2; the kernel needs all its
+ * workgroups resident at once, which another stream or process holding CUs can prevent); when a workgroup gives up,
+ * *d_sweeps = -1 and V holds what it held before the call (a finish kernel is the only writer of V) — the caller runs the
+ * same evaluation through pi_eval_sweeps.
  */
 int pi_policy_evaluation(pi_handle* h, float* V, const int32_t* policy, const uint8_t* term, float gamma,
                          double theta, int max_sweeps, int check_interval, int32_t* d_sweeps, float* d_delta,

@@ -120,7 +120,7 @@ class OracleLib:
                                                   _i32p, _i32p, ctypes.c_float, _i32p, _f32p]
             lib.oracle_improve_points.restype = None
         lib.oracle_run.argtypes = [_f32p, _f32p, ctypes.c_int32, _i32p, _f32p, _f32p, _u8p, _f32p,
-                                   _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                   _f32p, _i32p, _i32p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_int32, ctypes.c_int32, _f32p, _i64p, _i32p]
         lib.oracle_run.restype = None
 
@@ -253,7 +253,7 @@ class OracleLib:
         self._lib.oracle_run(_p(states, _f32p), _p(actions, _f32p), len(actions), _p(policy, _i32p),
                              _p(V, _f32p), _p(Vtmp, _f32p), _p(term, _u8p), _p(lo, _f32p), _p(hi, _f32p),
                              _p(shape, _i32p), _p(strides, _i32p), n, np.float32(gamma),
-                             np.float32(theta), max_eval_iter, max_pi_iter, _p(V_out, _f32p),
+                             float(theta), max_eval_iter, max_pi_iter, _p(V_out, _f32p),
                              _p(stats, _i64p), _p(per_iter, _i32p))
         return {
             "value_function": V_out, "policy": policy, "outer_iterations": int(stats[0]),

@@ -278,7 +278,7 @@ void oracle_improve_points(int64_t m, const float* coords, const float* actions,
  */
 void oracle_run(const float* states, const float* actions, int32_t n_actions, int32_t* policy,
                 float* V, float* Vtmp, const uint8_t* is_term, const float* lo, const float* hi,
-                const int32_t* g, const int32_t* st, int64_t n, float gamma, float theta,
+                const int32_t* g, const int32_t* st, int64_t n, float gamma, double theta,
                 int32_t max_eval_iter, int32_t max_pi_iter, float* V_out, int64_t* stats,
                 int32_t* sweeps_per_iter) {
     float* cur = V;
@@ -294,7 +294,7 @@ void oracle_run(const float* states, const float* actions, int32_t n_actions, in
             std::swap(cur, nxt);
             ++sweeps;
             if (i % 25 == 0 || i == max_eval_iter - 1)
-                if (delta < theta) break;
+                if ((double)delta < theta) break;      // :329 compares float(delta) with the config's Python float
         }
         total += sweeps;
         if (sweeps_per_iter) sweeps_per_iter[it] = sweeps;

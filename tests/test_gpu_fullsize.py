@@ -73,11 +73,11 @@ def _orders(cfg):
     has no tuned order (the measured differences were inside the noise): it is run once in a permuted order anyway."""
     cls = envs.ENVS[CONFIGS[cfg][0]]
     out = [("env-order", None)]
-    if cls.MEMORY_ORDER is not None:
+    if isinstance(cls.MEMORY_ORDER, tuple):
         out.append(("single-rank-order", tuple(cls.MEMORY_ORDER)))
     if cls.SHARDED_MEMORY_ORDER is not None and cls.SHARDED_MEMORY_ORDER != cls.MEMORY_ORDER:
         out.append(("sharded-order", tuple(cls.SHARDED_MEMORY_ORDER)))
-    if cls.MEMORY_ORDER is None:
+    if not isinstance(cls.MEMORY_ORDER, tuple):
         out.append(("permuted-order", (0, 2, 1, 3)))
     return out
 
@@ -186,6 +186,88 @@ def test_full_size_properties_and_oracle_windows_in_every_production_order(cfg, 
         assert int(d_changed.item()) == int(np.count_nonzero(best != old))
         assert torch.equal(d_p2[:a], d_pol[:a]) and torch.equal(d_p2[b:], d_pol[b:])   # nothing outside the range
         del d_p2
+    # ... and 2^20 states scattered uniformly over the WHOLE memory-order range (round 6: the windows above are 0.04 % of
+    # the grid, all at the ends and the middle of the range): one evaluation and one whole-grid improvement result
+    # against the oracle at exactly those states, bit for bit
+    d_p2 = d_pol.clone()
+    eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), tptr, 0, n, gamma, d_changed.data_ptr())
+    torch.cuda.synchronize()
+    _check_scattered_sample(f"{cfg} {order}", chk, bins, acts, shape, order, gamma, Vh, polh, termh, d_Vn, d_p2,
+                            seed=1000 + seed)
+    eng.close()
+
+
+SCATTER = 1 << 20
+
+
+def _check_scattered_sample(what, chk, bins, acts, shape, order, gamma, V_user, pol_user, term_user, d_Vn_mem, d_pol_new_mem,
+                            seed, m=SCATTER):
+    """`m` memory-order indices drawn uniformly (seeded) from the whole grid: the device's new values (one evaluation sweep
+    of (V_user, pol_user)) and new policy (one improvement sweep of V_user) at those states against oracle_eval_points /
+    oracle_improve_points.  The device arrays are in the engine's memory order, the host arrays in the user's."""
+    torch = _torch()
+    D, n = len(shape), int(np.prod(shape))
+    lo, hi, gshape, strides = oracle.grid_metadata(bins)
+    rng = np.random.default_rng(seed)
+    idx_mem = np.unique(rng.integers(0, n, size=m, dtype=np.int64))
+    ordr = tuple(range(D)) if order is None else tuple(order)
+    mem_shape = [shape[d] for d in ordr]
+    im = np.stack(np.unravel_index(idx_mem, mem_shape), axis=1)
+    iu = np.empty_like(im)
+    for k, d in enumerate(ordr):
+        iu[:, d] = im[:, k]
+    flat_user = np.ravel_multi_index(tuple(iu.T), shape)
+    coords = np.stack([bins[d][iu[:, d]] for d in range(D)], axis=1).astype(np.float32)
+    t = np.zeros(len(idx_mem), dtype=bool) if term_user is None else term_user[flat_user].astype(bool)
+    d_idx = torch.from_numpy(idx_mem).to(d_Vn_mem.device)
+    got_V = d_Vn_mem[d_idx].cpu().numpy()
+    got_P = d_pol_new_mem[d_idx].cpu().numpy()
+    want_V = chk.eval_points(coords, acts[pol_user[flat_user]], V_user, lo, hi, gshape, strides, gamma)
+    want_V[t] = V_user[flat_user][t]
+    H.assert_bits_equal(got_V, want_V, f"{what}: evaluation at {len(idx_mem)} scattered states")
+    best, _ = chk.improve_points(coords, acts, V_user, lo, hi, gshape, strides, gamma)
+    best[t] = pol_user[flat_user][t]
+    assert np.array_equal(got_P, best), f"{what}: improvement at {len(idx_mem)} scattered states"
+    return len(idx_mem)
+
+
+def test_c3_run_to_convergence_then_one_more_sweep_equals_the_oracle_on_a_scattered_sample(cuda_device):
+    """Round 6: the only oracle statement about a CONVERGED big-grid state.  C3's real run() (cartpole swing-up 50^4,
+    96 597 sweeps, ~5 s), then one further evaluation sweep and one further improvement sweep of the final (V, policy)
+    on the device against the oracle at 2^20 scattered states: bit for bit — and, the run having ended stable, the oracle
+    must find the final policy greedy at every sampled state."""
+    torch = _torch()
+    name, nb = "cartpole_swingup", 50
+    solver = envs.make(name, nb, device=cuda_device)
+    solver.run()
+    assert solver.stats.get("stable") is True and sum(solver.stats["sweeps_per_iter"]) == 96_597
+    n, D = solver.n_states, 4
+    V_user = np.ascontiguousarray(solver.value_function, dtype=np.float32)
+    pol_user = np.ascontiguousarray(solver.policy, dtype=np.int32)
+    # run() has released the device (reference :372-388): a fresh engine, in a permuted memory order for good measure
+    gamma = float(np.float32(solver.config.gamma))
+    bins = H.env_bins(name, (nb,) * D)
+    acts = np.asarray(solver.action_space, np.float32)
+    order = (0, 2, 1, 3)
+    eng = _native.Engine(D, [nb] * D, [b.min() for b in bins], [b.max() for b in bins], bins, acts,
+                         device=cuda_device.index or 0, order=order)
+    eng.compile(envs.dynamics_source(name))
+    states = oracle.states_from_bins(bins)
+    term_user, _ = H.terminal_mask(name, states)
+    del states
+    d_V = eng.to_memory(torch.from_numpy(V_user).to(cuda_device))
+    d_pol = eng.to_memory(torch.from_numpy(pol_user).to(cuda_device))
+    d_term = eng.to_memory(torch.from_numpy(term_user.astype(np.uint8)).to(cuda_device))
+    d_Vn = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    d_p2 = d_pol.clone()
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    eng.eval_sweep(d_V.data_ptr(), d_Vn.data_ptr(), d_pol.data_ptr(), d_term.data_ptr(), 0, n, gamma, 0)
+    eng.improve_sweep(d_V.data_ptr(), d_p2.data_ptr(), d_term.data_ptr(), 0, n, gamma, d_changed.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_changed.item()) == 0                               # stable: a further improvement changes nothing
+    m = _check_scattered_sample("c3 converged", H.oracle_for(name), bins, acts, (nb,) * D, order, gamma, V_user, pol_user,
+                                term_user, d_Vn, d_p2, seed=77)
+    assert m > 600_000
     eng.close()
 
 
@@ -261,3 +343,90 @@ def test_the_bench_path_in_its_memory_order_equals_the_identity_order_engine(nam
     assert torch.equal(got_P, want_P), f"{name}: policy differs from the identity-order engine"
     assert residual == want_residual and changed == want_changed
     solver._backend.close()
+
+
+def test_a_plugin_written_for_the_reference_gets_a_measured_memory_order_at_full_size(cuda_device, monkeypatch, tmp_path):
+    """Round 6 (reference contract :113-138): a subclass of CudaPolicyIteration6D that defines ONLY what the reference
+    asks of a plugin — `_dynamics_cuda_src` (the double cartpole's string) and `_terminal_fn(states)`; no MEMORY_ORDER, no
+    `_terminal_fn_axes` — on the 25^6 grid: its memory order is measured at construction (the cart's speed ends up along
+    the lanes), one evaluation and one improvement sweep equal the oracle at 2^18 scattered states bit for bit, and its
+    evaluation sweeps run within 5 % of the hand-set order of the built-in class."""
+    from dynamicprogramming_amd.solver import CudaPolicyIteration6D
+    torch = _torch()
+    monkeypatch.setattr(_native, "KERNEL_CACHE", tmp_path)          # measure here, whatever an earlier run cached
+    builtin = envs.DoubleCartPoleCuda
+
+    class ReferencePlugin(CudaPolicyIteration6D):
+        def _dynamics_cuda_src(self):
+            return envs.dynamics_source("double_cartpole")
+
+        def _terminal_fn(self, states):
+            x, t1, t2 = states[:, 0], states[:, 2], states[:, 4]
+            lim = 20.0 * np.pi / 180.0
+            return ((x < -2.4) | (x > 2.4) | (t1 < -lim) | (t1 > lim) | (t2 < -lim) | (t2 > lim)), 0.0
+
+    assert ReferencePlugin.MEMORY_ORDER is None and "_terminal_fn_axes" not in vars(ReferencePlugin)
+    nb, D = 25, 6
+    cfg = envs.CudaPIConfig(**builtin.CONFIG)
+    plug = ReferencePlugin(builtin.bins_space(nb), builtin.ACTIONS, cfg, device=cuda_device)
+    plug.states_space = None                                        # 5.9 GB of host memory the sweeps never needed
+    order = plug._order
+    assert order is not None and order[-1] == 1, f"expected the cart's speed along the lanes, got {order}"
+    cands = plug._order_tuning["candidates"]
+    assert cands[0]["order"] == list(range(D)) and min(c["eval_ms"] for c in cands) < 0.9 * cands[0]["eval_ms"]
+    n = plug.n_states
+    gamma = float(np.float32(cfg.gamma))
+
+    def bench_state(solver):
+        gen = torch.Generator(device="cpu").manual_seed(3)
+        V = torch.randn(n, generator=gen, dtype=torch.float32)
+        pol = torch.randint(0, solver.n_actions, (n,), generator=gen, dtype=torch.int32)
+        t_user = solver._to_user(solver.d_terminal_mask[:n]).bool().cpu()
+        V[t_user] = 0.0
+        pol[t_user] = 0
+        solver.d_value_function[:n].copy_(solver._to_memory(V.to(cuda_device)))
+        solver.d_new_value_function.copy_(solver.d_value_function)
+        solver.d_policy[:n].copy_(solver._to_memory(pol.to(cuda_device)))
+        return V.numpy(), pol.numpy(), t_user.numpy()
+
+    def sweep_ms(solver, k=10, groups=3):
+        best = float("inf")
+        for _ in range(groups):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            solver._evaluation_sweeps(k, gamma)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / k)
+        return best
+
+    V_user, pol_user, term_user = bench_state(plug)
+    # parity first: one evaluation sweep and one improvement sweep of the plugin's engine against the oracle
+    eng = plug._backend.engine
+    tptr = plug._mask_arg().data_ptr()
+    d_Vn = torch.full((n,), float("nan"), dtype=torch.float32, device=cuda_device)
+    d_p2 = plug.d_policy[:n].clone()
+    d_changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    eng.eval_sweep(plug.d_value_function.data_ptr(), d_Vn.data_ptr(), plug.d_policy.data_ptr(), tptr, 0, n, gamma, 0)
+    eng.improve_sweep(plug.d_value_function.data_ptr(), d_p2.data_ptr(), tptr, 0, n, gamma, d_changed.data_ptr())
+    torch.cuda.synchronize()
+    bins = H.env_bins("double_cartpole", (nb,) * D)
+    _check_scattered_sample("reference plugin 25^6", H.oracle_for("double_cartpole"), bins, np.asarray(builtin.ACTIONS, np.float32),
+                            (nb,) * D, order, gamma, V_user, pol_user, term_user, d_Vn, d_p2, seed=5, m=1 << 18)
+    del d_Vn, d_p2
+    # ... then speed: the bench state's evaluation sweeps, plugin against the built-in class with its hand-set order
+    hand = envs.make("double_cartpole", nb, device=cuda_device)
+    assert hand._order == tuple(builtin.MEMORY_ORDER)
+    bench_state(hand)
+    for solver in (plug, hand):                                    # the per-evaluation lists as policy_evaluation() brackets them
+        solver._backend.eval_begin(solver.d_policy, solver._mask_arg())
+    try:
+        sweep_ms(plug, groups=1), sweep_ms(hand, groups=1)           # warm
+        t_plug, t_hand = sweep_ms(plug), sweep_ms(hand)
+    finally:
+        plug._backend.eval_end()
+        hand._backend.eval_end()
+    print(f"[plugin order] measured {order}: {t_plug:.3f} ms per evaluation sweep; hand-set {hand._order}: {t_hand:.3f} ms")
+    assert t_plug <= 1.05 * t_hand, f"measured order {order} {t_plug:.3f} ms vs hand-set {t_hand:.3f} ms"
+    plug._backend.close()
+    hand._backend.close()

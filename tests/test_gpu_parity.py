@@ -1131,20 +1131,35 @@ def test_memory_order_full_runs_equal_the_oracle(name, shape, order, world, cuda
 
 @pytest.mark.parametrize("name,bins,lane", [("double_cartpole_swingup", 11, 1), ("double_cartpole", 11, 1),
                                              ("double_pendulum_swingup", 24, None), ("pendulum", 40, None)])
-def test_memory_order_auto_picks_a_lane_dimension_from_the_dynamics(name, bins, lane, cuda_device, monkeypatch):
-    """PI_MI355_ORDER=auto: the lane dimension of an env nobody tuned is the one along which a wave's successors stay
-    together (measured on the device with the plugin itself); for the double cartpole that is the cart's speed — what
-    the exhaustive measurement finds — dimension 0 stays slowest, and the run's results are the oracle's in any case."""
+def test_memory_order_auto_measures_candidates_derived_from_the_dynamics(name, bins, lane, cuda_device, monkeypatch, tmp_path):
+    """PI_MI355_ORDER=auto (and, round 6, every big plugin without a MEMORY_ORDER of its own): a handful of candidate orders
+    derived from the plugin's own dynamics — the lane dimension is the one along which a wave's successors stay together;
+    for the double cartpole that is the cart's speed, what the exhaustive measurement finds, with the cart's position
+    tried second-fastest — each timed on the device; the decision is cached; the run's results are the oracle's whatever
+    order wins."""
     monkeypatch.setenv("PI_MI355_ORDER", "auto")
+    monkeypatch.setattr(_native, "KERNEL_CACHE", tmp_path)
     cls = envs.ENVS[name]
+    D = cls._D
     cfg_kw = {**cls.CONFIG, "max_pi_iter": 2, "max_eval_iter": 40}
     s = cls(cls.bins_space(bins), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
-    order = s._order if s._order is not None else tuple(range(cls._D))
-    assert sorted(order) == list(range(cls._D)) and order[0] == 0
+    order = s._order if s._order is not None else tuple(range(D))
+    rec = s._order_tuning
+    cands = [tuple(r["order"]) for r in rec["candidates"]]
+    assert sorted(order) == list(range(D)) and order in cands and cands[0] == tuple(range(D))
+    assert all(sorted(c) == list(range(D)) for c in cands) and len(set(cands)) == len(cands) and len(cands) <= 14
+    assert all(r["eval_ms"] > 0 for r in rec["candidates"])
     if lane is not None:
-        assert order[-1] == lane and list(order[:-1]) == [d for d in range(cls._D) if d != lane]
+        with_lane = [c for c in cands if c[-1] == lane]
+        assert len(with_lane) >= 4 and any(c[-2:] == (0, lane) for c in with_lane)        # (.., x, x_dot) is tried
+    # the decision is cached beside the code objects: a second solver reads it instead of measuring again
+    files = list(tmp_path.glob("order_*.json"))
+    assert len(files) == 1
+    s2 = cls(cls.bins_space(bins), cls.ACTIONS, envs.CudaPIConfig(**cfg_kw), device=cuda_device)
+    assert s2._order == s._order and s2._order_tuning["candidates"] == rec["candidates"]
+    s2._backend.close()
     s.run()
-    tables = H.env_bins(name, (bins,) * cls._D)
+    tables = H.env_bins(name, (bins,) * D)
     lo, hi, gshape, strides = oracle.grid_metadata(tables)
     states = oracle.states_from_bins(tables)
     term, tval = H.terminal_mask(name, states)
@@ -1201,16 +1216,39 @@ def test_one_launch_evaluation_with_any_look_interval(name, bins, xcd, interval,
 
 def test_one_launch_evaluation_gives_up_loudly_instead_of_hanging(cuda_device, monkeypatch):
     """Every device-side wait of the dataflow kernel is bounded: with a time limit no hand-off can meet (100 ns) a wave
-    gives up, raises the status word, every other wave leaves at its next poll, the launch ENDS, *d_sweeps = -1 and
-    the solver raises — and the next evaluation with a sane limit is unaffected."""
+    gives up, raises the status word, every other wave leaves at its next poll, the launch ENDS with *d_sweeps = -1 and —
+    round 6 — V untouched: the finish kernel is its only writer.  The solver then runs the evaluation sweep
+    by sweep (same sweeps, residual and V as a solver that never had the kernel), stops trying the kernel after two such
+    launches, and an evaluation with a sane limit on a fresh solver is unaffected."""
     torch = _torch()
     monkeypatch.setenv("PI_MI355_XCD", "0")              # the XCD-local kernel has its own fallback: the dataflow kernel is the one that gives up
     s = envs.make("pendulum", 200, device=cuda_device)
     assert s._backend.engine.info(19) > 0 and s._backend.engine.info(30) == 0
+    n = s.n_states
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    V0 = torch.randn(n, generator=gen, dtype=torch.float32).to(cuda_device)
+    s.d_value_function[:n].copy_(V0)
+    s.d_new_value_function.copy_(s.d_value_function)
     monkeypatch.setenv("PI_MI355_FLOW_TIMEOUT", "0.0000001")
-    with pytest.raises(RuntimeError, match="gave up waiting"):
-        s.policy_evaluation()
+    # through the C ABI: the launch ends, reports -1 and leaves V alone
+    assert s._backend.policy_evaluation(s.d_value_function, s.d_policy, s._mask_arg(), 0.9, 1e-4, 100, 25) is None
     torch.cuda.synchronize()
+    assert torch.equal(s.d_value_function[:n].view(torch.int32), V0.view(torch.int32)), "a failed launch touched V"
+    # through the solver: the same evaluation, sweep by sweep
+    delta = s.policy_evaluation()
+    assert s._backend.one_launch_failures == 2 and not s._backend.resident       # not tried a third time
+    monkeypatch.setenv("PI_MI355_RESIDENT", "0")
+    plain = envs.make("pendulum", 200, device=cuda_device)
+    assert not plain._backend.resident
+    plain.d_value_function[:n].copy_(V0)
+    plain.d_new_value_function.copy_(plain.d_value_function)
+    want = plain.policy_evaluation()
+    assert np.float32(delta) == np.float32(want) and s.stats["sweeps_per_iter"][-1] == plain.stats["sweeps_per_iter"][-1]
+    assert torch.equal(s.d_value_function.view(torch.int32), plain.d_value_function.view(torch.int32))
+    plain._backend.close()
+    s._backend.close()
+    monkeypatch.delenv("PI_MI355_RESIDENT")
+    s = envs.make("pendulum", 200, device=cuda_device)
     monkeypatch.delenv("PI_MI355_FLOW_TIMEOUT")
     s.d_value_function.zero_()
     s.d_new_value_function.zero_()
