@@ -390,22 +390,27 @@ class _CudaPolicyIterationBase(abc.ABC):
     def _candidate_orders(self, spread):
         """A handful of memory orders worth timing, from the spreads of `_lane_spreads`.  Lane dimension: the one along
         which a wave's successors stay together — the smallest total spread over the OTHER dimensions (double cartpole:
-        0.9 cells with x_dot along the lanes, 5-9 with an angle or an angular speed), ties to the env's own last
-        dimension; the runner-up as well when it is within a quarter of the best.  Its PARTNER — the dimension a wave's
+        0 cells with x along the lanes, 0.9 with x_dot, 5-9 with an angle or an angular speed), ties to the env's own
+        last dimension — and the runner-up.  Its PARTNER — the dimension a wave's
         successors spread over most, the position a lane velocity moves — is tried second-fastest (double cartpole:
         (.., x, x_dot) is worth 8-10 % over (x, .., x_dot), profiles/r04/dim_order.txt), every remaining dimension is
         tried as the slowest, and the env's own order is always among the candidates."""
         D = self._D
         total = {d: sum(v for k, v in spread[d].items() if k != d) for d in range(D)}
         ranked = sorted(range(D), key=lambda d: (total[d], -d))
-        lanes = [ranked[0]] + [d for d in ranked[1:2] if total[d] <= 1.25 * total[ranked[0]] + 1e-9]
+        lanes = ranked[:2] if D >= 3 else ranked[:1]
         out = [tuple(range(D))]
         for lane in lanes:
             rest = [k for k in range(D) if k != lane]
             out.append(tuple(rest + [lane]))
             if D < 3:
                 continue
+            # the partner: where a wave along `lane` spreads most; a wave that does not spread at all (a position along
+            # the lanes: every successor moves by the same dt * velocity) is paired with the dimension that spreads
+            # over IT — its velocity
             partner = max(rest, key=lambda k: (spread[lane][k], k))
+            if spread[lane][partner] < 0.25:
+                partner = max(rest, key=lambda k: (spread[k][lane], k))
             others = [k for k in rest if k != partner]
             for slow in others:
                 out.append(tuple([slow] + [k for k in others if k != slow] + [partner, lane]))

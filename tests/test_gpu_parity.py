@@ -251,6 +251,9 @@ def test_c2_full_run_matches_oracle(cuda_device):
     cfg = envs.CudaPIConfig(**cls.CONFIG)
     solver = envs.make("pendulum", 200, device=cuda_device)
     solver.run()
+    # the run compared with the oracle below IS the one-launch path (pi_policy_iteration on the XCD-local kernel): one whole
+    # run launched, no fallback to the round-by-round loop (pi_info 33 / 32, read when run() released the device)
+    assert solver._backend.whole_runs == 1 and solver._backend.xcd_fallbacks == 0
     bins = H.env_bins("pendulum", (200, 200))
     lo, hi, gshape, strides = oracle.grid_metadata(bins)
     states = oracle.states_from_bins(bins)
@@ -1152,6 +1155,7 @@ def test_memory_order_auto_measures_candidates_derived_from_the_dynamics(name, b
     if lane is not None:
         with_lane = [c for c in cands if c[-1] == lane]
         assert len(with_lane) >= 4 and any(c[-2:] == (0, lane) for c in with_lane)        # (.., x, x_dot) is tried
+        assert any(c[-2:] == (lane, 0) for c in cands)                                     # ... and so is (.., x_dot, x)
     # the decision is cached beside the code objects: a second solver reads it instead of measuring again
     files = list(tmp_path.glob("order_*.json"))
     assert len(files) == 1
