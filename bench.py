@@ -291,9 +291,28 @@ def build_roofline(dom: dict, khash: str, prof_path, compulsory_per_state: float
                 "peak_source": "MI355X_MICROARCH.md: HBM3E 8 TB/s; VALU 1228.8 G wave64 instr/s (2 cycles x 1024 SIMDs x "
                                "2.4 GHz); vector-memory path one wave-wide load per 16 cycles per CU = 38.4 G/s"}
     units = dom.get("units")
+    sec = dom["avg_launch_ms"] * 1e-3
+    # compulsory bytes (every V value read once, V' written, the policy entry, the mask byte) against 8 TB/s: the fraction a
+    # traffic cut cannot lower — `frac` (measured traffic, re-fetches included) goes DOWN when re-fetches are removed
+    roofline["frac_hbm_compulsory"] = compulsory / sec / 1e9 / HBM_PEAK_GBS
     if units:
         roofline["units"] = units
         roofline["clock_GHz_under_profiler"] = dom.get("clock_GHz_under_profiler")
+        # the binding floor: the time each unit needs at the very least for this launch's instruction / load / byte
+        # counts (same committed profile), the largest of them, and how close the launch is to it
+        floor = {"hbm_compulsory_ms": compulsory / (HBM_PEAK_GBS * 1e9) * 1e3}
+        if "valu" in units:
+            floor["valu_ms"] = units["valu"]["insts_per_wave"] * units["valu"]["waves_per_launch"] / (VALU_PEAK_GIPS * 1e9) * 1e3
+        if "l1" in units:
+            floor["load_issue_ms"] = units["l1"]["loads_per_launch"] / (TCP_PEAK_GLOADS * 1e9) * 1e3
+        names = {"valu_ms": "valu-issue", "load_issue_ms": "l1-load-issue", "hbm_compulsory_ms": "hbm (compulsory bytes)"}
+        top = max(floor, key=lambda k: floor[k])
+        floor["max"] = floor[top]
+        floor["binding"] = names[top]
+        roofline["floor"] = floor
+        roofline["frac_of_floor"] = floor["max"] / dom["avg_launch_ms"]
+        roofline["bound_note"] = ("`bound` names the roofline the north star prices this path against (HBM); the unit whose "
+                                  "floor is highest is floor.binding, and frac_of_floor = that floor / the measured launch")
         name = max(units, key=lambda u: units[u]["frac"])
         roofline["most_utilised_unit"] = {"name": {"valu": "valu-issue", "l1": "l1-load-issue", "hbm": "hbm"}[name],
                                           "frac": units[name]["frac"], "achieved": units[name]["achieved"],
@@ -412,7 +431,9 @@ def measure_extra_config(label: str, env: str, bins: int, steps: int, warmup: in
            "roofline": {"kernel": dominant, "avg_launch_ms": dom_ms, "frac_hbm": roof.get("frac_hbm"),
                         "hbm_frac_raw": roof.get("hbm_frac_raw"), "traffic_vs_compulsory": roof.get("traffic_vs_compulsory"),
                         "valu_frac": (units.get("valu") or {}).get("frac"), "l1_load_issue_frac": (units.get("l1") or {}).get("frac"),
-                        "most_utilised_unit": roof.get("most_utilised_unit"), "profile": prof_path},
+                        "most_utilised_unit": roof.get("most_utilised_unit"), "profile": prof_path,
+                        "frac_hbm_compulsory": roof.get("frac_hbm_compulsory"), "floor": roof.get("floor"),
+                        "frac_of_floor": roof.get("frac_of_floor")},
            "check": {"last_residual": float(solver._d_delta.item()), "last_changed": int(solver._d_changed.item()),
                      "live_list_states": live_states},
            "wall_seconds": None}
@@ -437,6 +458,53 @@ def measure_extra_config(label: str, env: str, bins: int, steps: int, warmup: in
     del solver
     torch.cuda.empty_cache()
     out["wall_seconds"] = time.perf_counter() - t_wall
+    return out
+
+
+# Runs to convergence (the metric's "sweeps-to-converge" half) the default command makes after the timed region, in this
+# order, each only if its estimated wall seconds still fit --time-budget: (label, env, bins, estimated seconds on one MI355X).
+# What every run must reproduce — policy-iteration rounds, evaluation sweeps, sha256[:16] of the bytes of V and of the policy
+# (host side, the env's own order) — has been the same since round 2 (profiles/r05/full_runs.txt): results are a property of
+# the arithmetic, not of the schedule, the memory order or the kernel family that ran them.
+FULL_RUNS = [
+    ("c3", "cartpole_swingup", 50, 8.0),
+    ("c4", "double_pendulum_swingup", 80, 45.0),
+    ("c5", "double_cartpole", 25, 185.0),
+]
+FULL_RUN_EXPECTED = {
+    "c3": {"pi_iterations": 22, "eval_sweeps": 96597, "sha256_V": "b02a3b180957e958", "sha256_policy": "fa86d09d962901e2"},
+    "c4": {"pi_iterations": 19, "eval_sweeps": 100668, "sha256_V": "f4273576334e09b3", "sha256_policy": "956b9129034ba3ba"},
+    "c5": {"pi_iterations": 15, "eval_sweeps": 65540, "sha256_V": "ef4e764816a78bd4", "sha256_policy": "1674736d1a6f6ec6"},
+}
+
+
+def run_to_convergence(label: str, env: str, bins: int, dev) -> dict:
+    """One full run() of (env, bins) from the env's initial state with its own settings through the product path: rounds,
+    sweeps, wall seconds and the digests of the results, compared with the committed ones (reference run() :357-370)."""
+    import hashlib
+    import torch
+    from dynamicprogramming_amd import envs
+    cls = envs.ENVS[env]
+    fresh = envs.make(env, bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
+    n, nA = fresh.n_states, fresh.n_actions
+    torch.cuda.synchronize()
+    t_run = time.perf_counter()
+    fresh.run()
+    t_run = time.perf_counter() - t_run
+    st = fresh.stats
+    out = {"env": env, "bins": bins, "states": n, "pi_iterations": st["pi_iterations"], "eval_sweeps": st["eval_sweeps"],
+           "improve_sweeps": st["improve_sweeps"], "stable": st.get("stable"), "seconds": t_run,
+           "backups_per_s": n * (st["eval_sweeps"] + st["improve_sweeps"] * nA) / t_run,
+           "us_per_eval_sweep": t_run / max(st["eval_sweeps"], 1) * 1e6,
+           "sha256_V": hashlib.sha256(fresh.value_function.tobytes()).hexdigest()[:16],
+           "sha256_policy": hashlib.sha256(fresh.policy.tobytes()).hexdigest()[:16],
+           "settings": dict(cls.CONFIG)}
+    want = FULL_RUN_EXPECTED.get(label)
+    if want and (env, bins) == next((e, b) for l, e, b, _ in FULL_RUNS if l == label):
+        out["expected"] = want
+        out["matches_committed_digests"] = all(out[k] == v for k, v in want.items())
+    del fresh
+    torch.cuda.empty_cache()
     return out
 
 
@@ -957,7 +1025,6 @@ def main() -> None:
     khash = _native.kernel_source_hash()
     t_start = T_PROCESS_START
     extra_configs, extra_skipped = [], []
-    full_run_cost = 45.0 if (args.env, args.bins) == (ENV, BINS) else 0.0
     cpu_cost = 0.0 if args.no_cpu_baseline else 25.0
     if world == 1 and not args.no_extra_configs and (args.env, args.bins) == (ENV, BINS):
         # the headline's device arrays are not needed while the extras run (25^6 wants ~4 GB): keep them, 288 GB is plenty
@@ -971,30 +1038,33 @@ def main() -> None:
             except Exception as exc:                  # never lose the headline over an extra
                 extra_skipped.append({"label": label, "reason": repr(exc)})
 
-    # ── sweeps-to-converge (optional: a full run() from V = 0 with the env's own settings) ───
+    # ── sweeps-to-converge: full run()s from the envs' initial states with their own settings (N = 1, outside the timed
+    # region).  Default config: C3 -> C4 (the headline, `sweeps_to_converge`) -> C5, each only while its estimate fits the
+    # time budget; another --env / --bins: that config alone.  Digests of V and the policy are compared with the committed ones.
     full_run = None
-    if world == 1 and not args.no_full_run and n >= (1 << 27) and not args.full_run:
-        full_run = {"skipped": f"{n} states: a run to convergence takes minutes; pass --full-run"}
-    elif (world == 1 and not args.no_full_run and not args.full_run
-          and time.perf_counter() - t_start + full_run_cost + cpu_cost > args.time_budget):
-        full_run = {"skipped": f"time budget: {time.perf_counter() - t_start:.0f} s spent of {args.time_budget:.0f}; "
-                               f"pass --full-run (profiles/r05/full_runs.txt holds the measured runs)"}
-    elif world == 1 and not args.no_full_run:
-        try:
-            fresh = envs.make(args.env, args.bins, config=envs.CudaPIConfig(**cls.CONFIG), device=dev)
-            torch.cuda.synchronize()
-            t_run = time.perf_counter()
-            fresh.run()
-            t_run = time.perf_counter() - t_run
-            st = fresh.stats
-            full_run = {"pi_iterations": st["pi_iterations"], "eval_sweeps": st["eval_sweeps"],
-                        "improve_sweeps": st["improve_sweeps"], "stable": st.get("stable"), "seconds": t_run,
-                        "backups_per_s": n * (st["eval_sweeps"] + st["improve_sweeps"] * nA) / t_run,
-                        "us_per_eval_sweep": t_run / max(st["eval_sweeps"], 1) * 1e6,
-                        "settings": dict(cls.CONFIG)}
-            del fresh
-        except Exception as exc:                      # never lose the timed result over the extra run
-            full_run = {"error": repr(exc)}
+    full_runs, full_runs_skipped = {}, []
+    if world == 1 and not args.no_full_run:
+        default_cfg = (args.env, args.bins) == (ENV, BINS)
+        plan = FULL_RUNS if default_cfg else [("this", args.env, args.bins, 0.0)]
+        for label, r_env, r_bins, est in plan:
+            spent = time.perf_counter() - t_start
+            if not default_cfg and n >= (1 << 27) and not args.full_run:
+                full_runs_skipped.append({"label": label, "reason": f"{n} states: a run to convergence takes minutes; pass --full-run"})
+                continue
+            if not args.full_run and spent + est + cpu_cost > args.time_budget:
+                full_runs_skipped.append({"label": label, "reason": f"time budget: {spent:.0f} s spent of {args.time_budget:.0f}, "
+                                                                    f"this run needs ~{est:.0f} s; pass --full-run "
+                                                                    f"(profiles/r05/full_runs.txt holds the measured runs)"})
+                continue
+            try:
+                full_runs[label] = run_to_convergence(label, r_env, r_bins, dev)
+            except Exception as exc:                  # never lose the timed result over an extra run
+                full_runs[label] = {"error": repr(exc)}
+        key = "c4" if default_cfg else "this"
+        full_run = full_runs.get(key) or next(({"skipped": x["reason"]} for x in full_runs_skipped if x["label"] == key), None)
+        for x in extra_configs:                       # C3 / C5: beside their sweep timings as well
+            if x["label"] in full_runs and "full_run" not in x:
+                x["full_run"] = full_runs[x["label"]]
 
     # ── roofline ──────────────────────────────────────────────────────────────────────────
     prof, prof_path = (None, None) if minimal else load_profile(args.env, args.bins, n, khash, order=eng.order)
@@ -1104,6 +1174,8 @@ def main() -> None:
         "kernels": kernels,
         "time_share_ms": share,
         "sweeps_to_converge": full_run,
+        "full_runs": full_runs,
+        "full_runs_skipped": full_runs_skipped,
         "extra_configs": extra_configs,
         "extra_configs_skipped": extra_skipped,
         "eval_backups_per_s": states_per_launch * world / (eval_ms * 1e-3),
@@ -1123,7 +1195,11 @@ def main() -> None:
             x["label"]: {"env": x["env"], "bins": x["bins"], "eval_ms": round(x["eval_ms"], 5), "improve_ms": round(x["improve_ms"], 5),
                          "backups_per_s": float(f"{x['backups_per_s']:.4g}"), "frac_hbm": x["roofline"]["frac_hbm"],
                          "hbm_frac_raw": x["roofline"]["hbm_frac_raw"], "valu_frac": x["roofline"]["valu_frac"],
-                         "l1_load_issue_frac": x["roofline"]["l1_load_issue_frac"]} for x in extra_configs}
+                         "l1_load_issue_frac": x["roofline"]["l1_load_issue_frac"],
+                         "frac_hbm_compulsory": x["roofline"].get("frac_hbm_compulsory"),
+                         "traffic_vs_compulsory": x["roofline"].get("traffic_vs_compulsory"),
+                         "floor": x["roofline"].get("floor"), "frac_of_floor": x["roofline"].get("frac_of_floor")}
+            for x in extra_configs}
     if rank == 0 and not args.no_cpu_baseline and not minimal and os.environ.get("PI_BENCH_BONUS") != "1":   # rank 0's host cores; the other ranks wait at the barrier below
         out["cpu_baseline"] = cpu_baseline(args.env, args.bins, args.cpu_sample)
     if rank == 0:
@@ -1132,6 +1208,12 @@ def main() -> None:
             brief = [f"{x['label']}: eval {x['eval_ms']:.4f} ms, improve {x['improve_ms']:.4f} ms, {x['backups_per_s']:.3e} backups/s, "
                      f"frac_hbm {x['roofline']['frac_hbm']}" for x in extra_configs]
             print("bench.py extra_configs | " + " | ".join(brief + [f"{x['label']}: skipped ({x['reason']})" for x in extra_skipped]),
+                  file=sys.stderr, flush=True)
+        if full_runs or full_runs_skipped:
+            brief = [f"{k}: {v.get('eval_sweeps')} sweeps in {v.get('pi_iterations')} rounds, {v.get('seconds', float('nan')):.2f} s, "
+                     f"digests {'match' if v.get('matches_committed_digests') else v.get('matches_committed_digests')}"
+                     if "error" not in v else f"{k}: {v['error']}" for k, v in full_runs.items()]
+            print("bench.py full_runs | " + " | ".join(brief + [f"{x['label']}: skipped ({x['reason']})" for x in full_runs_skipped]),
                   file=sys.stderr, flush=True)
     if world > 1:
         # tear down in a defined order: drain the GPU, let every rank arrive, destroy the library's

@@ -138,9 +138,11 @@ struct pi_handle {
     hipFunction_t f_flow = nullptr, f_flow_finish = nullptr;
     void* d_flow = nullptr;
     size_t flow_bytes = 0;
-    // XCD-local evaluation (pi_eval_xcd_kernel): all workgroups on one XCD, a counter in that XCD's L2 as the barrier.
-    // xcd: this grid qualifies; xcd_off: switched off after repeated failures.  d_xcd: ring of versions | control words
-    // (owned).  Counters for pi_info 30-32.
+    // XCD-local evaluation / whole run (pi_xcd_kernel, csrc/pi_onelaunch_kernels.hip): one 1 024-thread workgroup per CU of
+    // ONE XCD, the iterates as tagged granules through that XCD's L2, flag granules as the barrier every 32nd sweep.
+    // xcd: this grid qualifies; xcd_off: switched off after repeated failures (pi_policy_evaluation counts its own; a failed
+    // whole run is reported back through pi_set_option 8).  d_xcd: ring of xcd_ring versions | scratch policy | control
+    // words (owned).  Counters for pi_info 30-33.
     bool xcd = false, xcd_off = false;
     int xcd_states = 1024;                               // states per workgroup (PI_XCD_S)
     int xcd_ring = 64;                                   // granule versions of V the kernel keeps (PI_XCD_RING)

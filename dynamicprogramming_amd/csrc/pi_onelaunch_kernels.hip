@@ -649,6 +649,9 @@ pi_eval_flow_kernel(float* __restrict__ Va, const int* __restrict__ policy, cons
 #define PI_XCD_CTL_DONE 80                                // sweeps done, residual bits, iterations, stable (workgroup 0, at the end)
 #define PI_XCD_CTL_FLAGS 128                              // 2 banks x 64 flag granules of 8 bytes (256 words)
 #define PI_XCD_CTL_WORDS (PI_XCD_CTL_FLAGS + 256)
+#ifdef PI_XCD_HOST_CTL_WORDS
+static_assert(PI_XCD_CTL_WORDS == PI_XCD_HOST_CTL_WORDS, "the host allocates another control block than this kernel lays out");
+#endif
 #define PI_XCD_NPAD (((unsigned int)PI_GRID.n + 15u) & ~15u)      // granules per version: whole 128-byte lines
 typedef unsigned int PiQuad __attribute__((ext_vector_type(4)));   // two adjacent granules: {bits, tag, bits, tag}
 // One workgroup per CU (PI_XCD_PAD floats of LDS that nothing else needs see to it), PI_XCD_S states per workgroup —

@@ -153,7 +153,7 @@ class HipSweepBackend:
         round-by-round loop."""
         return self.resident and self.engine.info(34) > 0 and os.environ.get("PI_MI355_WHOLE_RUN", "1") != "0"
 
-    def policy_iteration(self, V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter):
+    def policy_iteration(self, V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter, retried=False):
         """The whole run on the device (pi_policy_iteration).  Returns (rounds done, stable, [(sweeps, residual,
         entries changed) per round]) — or None when the launch could not go through (placement, a bounded wait):
         V and the policy are untouched then and the caller runs the loop itself.  One host synchronisation."""
@@ -164,6 +164,15 @@ class HipSweepBackend:
         host = out.cpu().numpy()
         rounds = int(host[0])
         if rounds < 0:
+            # the XCD-local launch did not go through (placement, a bounded wait): V and the policy are untouched.  The
+            # library cannot count that itself (the call is asynchronous): report it, and where one CU's LDS holds the
+            # grid run the whole-run kernel that cannot fail instead of going back to the round-by-round loop.
+            if not retried and self.engine.info(13) > 0 and self.engine.info(14) == 1:
+                self.engine.set_option(8, 2)
+                return self.policy_iteration(V, policy, term, gamma, theta, max_eval_sweeps, check_interval, max_pi_iter,
+                                             retried=True)
+            if not retried:
+                self.engine.set_option(8, 1)
             return None
         log = host[2:2 + 4 * rounds].reshape(rounds, 4)
         residuals = log[:, 1].copy().view(np.float32)

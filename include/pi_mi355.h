@@ -413,6 +413,8 @@ int pi_infer_query(pi_infer* h, const float* d_points, int64_t m, float* d_actio
  * small grids in the LDS-resident kernel (0 | 1), 5 = build the fused swept-first kernel of the peer-to-peer exchange
  * now (value != 0; after pi_compile; a compile check on host-only handles), 6 = keep the live-state list of
  * pi_prepare_mask even when it fills no idle lanes (0 | 1; the fused exchange of a sharded run delivers from the list sweeps),
+ * 8 = report that the last pi_policy_iteration launch on the XCD-local kernel did not go through (1: count it — two
+ * failures switch that kernel off for the handle —, 2: and switch it off now),
  * 7 = STRIP SCHEDULE of the sweeps: states per period (see pi_plan_schedule; -1 = the library's choice for the grid, the
  * default; 0 = slab schedule; PI_MI355_STRIP in the environment at pi_create sets the same), 4 = MEMORY ORDER of the dimensions (before pi_compile, once):
  * digit k (base 8) of the value is the dimension — numbered as in pi_create and in step_dynamics' arguments —

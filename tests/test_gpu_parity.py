@@ -710,22 +710,30 @@ def test_whole_run_in_one_launch_through_the_c_abi(name, bins, rounds, max_eval,
 
 def test_whole_run_falls_back_when_it_cannot_be_placed(cuda_device, monkeypatch):
     """Every wait of the XCD-local kernel is bounded and nothing is written before a clean end: with a time limit no
-    barrier can meet (100 ns) the one-launch run reports failure with V and the policy untouched, run() goes on round by
-    round, the evaluations fail the same way twice, the form is switched off and the dataflow kernel finishes the run —
-    with the results of the sweep-by-sweep loop."""
+    barrier can meet (100 ns) the one-launch run reports failure with V and the policy untouched (and, round 6, is COUNTED:
+    pi_set_option 8), run() goes on round by round, the first evaluation fails the same way — the second failure: the form
+    is switched off — and the dataflow kernel finishes the run with the results of the sweep-by-sweep loop."""
     monkeypatch.setenv("PI_MI355_XCD_TIMEOUT", "0.0000001")
     cfg = envs.CudaPIConfig(**dict(envs.ENVS["mountain_car"].CONFIG, max_pi_iter=4))
     s = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
     assert s._backend.whole_run
     s.run()
-    assert (s._backend.whole_runs, s._backend.xcd_evaluations, s._backend.xcd_fallbacks) == (1, 2, 2)
+    assert (s._backend.whole_runs, s._backend.xcd_evaluations, s._backend.xcd_fallbacks) == (1, 1, 2)
+    # a grid one CU's LDS holds as well (pendulum 80 x 80 prefers the 32 CUs of an XCD): the failed launch is followed by
+    # the LDS-resident whole-run kernel, which cannot fail — still no round-by-round loop
+    cfg2 = envs.CudaPIConfig(**dict(envs.ENVS["pendulum"].CONFIG, max_pi_iter=4))
+    s2 = envs.make("pendulum", 80, config=cfg2, device=cuda_device)
+    assert s2._backend.whole_run and s2._backend.engine.info(30) > 0 and s2._backend.engine.info(13) > 0
+    s2.run()
+    assert (s2._backend.whole_runs, s2._backend.xcd_evaluations, s2._backend.xcd_fallbacks) == (2, 0, 1)
     monkeypatch.delenv("PI_MI355_XCD_TIMEOUT")
     monkeypatch.setenv("PI_MI355_RESIDENT", "0")
-    plain = envs.make("mountain_car", 113, config=cfg, device=cuda_device)
-    plain.run()
-    assert s.stats["sweeps_per_iter"] == plain.stats["sweeps_per_iter"] and s.stats["stable"] == plain.stats["stable"]
-    H.assert_bits_equal(s.value_function, plain.value_function, "V after the fallback")
-    assert np.array_equal(s.policy, plain.policy)
+    for solver, (name, bins, c) in ((s, ("mountain_car", 113, cfg)), (s2, ("pendulum", 80, cfg2))):
+        plain = envs.make(name, bins, config=c, device=cuda_device)
+        plain.run()
+        assert solver.stats["sweeps_per_iter"] == plain.stats["sweeps_per_iter"] and solver.stats["stable"] == plain.stats["stable"]
+        H.assert_bits_equal(solver.value_function, plain.value_function, f"{name}: V after the fallback")
+        assert np.array_equal(solver.policy, plain.policy)
 
 
 def test_a_subclass_with_its_own_improvement_step_is_called_round_by_round(cuda_device):
