@@ -84,7 +84,6 @@ SIGNATURES = {
     "pi_prepare_mask": (ctypes.c_int, [_vp, _vp, _vp]),
     "pi_prepare_mask_range": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     "pi_live_list": (ctypes.c_int64, [_vp, _vp, ctypes.c_int64, _vp]),
-    "pi_set_live_order": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
     "pi_eval_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "pi_eval_end": (ctypes.c_int, [_vp]),
 }
@@ -282,10 +281,6 @@ class Engine:
         if m < 0:
             raise NativeError(f"pi_live_list failed: {last_error()}")
         return m
-
-    def set_live_order(self, d_list, count, stream=0) -> None:
-        """The list sweeps visit the listed live states in the order of the device list at `d_list` (pi_set_live_order)."""
-        _check(lib().pi_set_live_order(self._h, d_list, int(count), stream or None), "pi_set_live_order")
 
     def eval_begin(self, policy, term, stream=0) -> int:
         """Start of one policy evaluation under the policy at `policy`: returns the length of the shorter list the

@@ -159,7 +159,6 @@ struct pi_handle {
     int32_t* d_live = nullptr;
     int64_t live_count = 0;
     bool live_force = false;             // pi_set_option 6: keep the list whatever the share of idle lanes
-    bool live_permuted = false;          // pi_set_live_order: the list is in a traversal order of the caller's, not ascending
     int64_t live_lo = 0, live_hi = 0;    // the state range the list covers (pi_prepare_mask_range; the whole grid otherwise)
     // pi_eval_begin .. pi_eval_end: the live states that bootstrap under the policy at eval_policy (device list,
     // capacity live_count); eval_count < 0: none.  eval_holds: buffers every live state of which has been written

@@ -132,14 +132,6 @@ int pi_prepare_mask_range(pi_handle* h, const uint8_t* d_term, int64_t s_begin, 
  * d_out (device, `capacity` entries) on `stream`; returns its length (0: no list is in use; d_out == NULL: length only;
  * -1: error).  For inspection and tests: the sweeps use the list inside the library. */
 int64_t pi_live_list(pi_handle* h, int32_t* d_out, int64_t capacity, void* stream);
-/* Replace the ORDER of the list pi_prepare_mask built: d_list (device, `count` == pi_info 16 entries) must hold exactly the
- * listed states, in the order the list sweeps — lane k of a launch takes state list[k] — are to visit them.  The order of a
- * Jacobi sweep changes which lines of V an XCD's L2 still holds when a state's successor cell asks for them, never a result
- * (every listed state is still backed up exactly once per sweep from the previous iterate).  From then on the list serves
- * launches over the whole listed range only; sub-range launches take the state-order kernels.  The library does not check
- * that d_list is a permutation of its list: a caller that drops or repeats a state gets sweeps that skip or repeat it.
- * pi_prepare_mask restores the ascending order.  No reference counterpart (one thread per state in index order, :305-318). */
-int pi_set_live_order(pi_handle* h, const int32_t* d_list, int64_t count, void* stream);
 
 /*
  * Optional bracket around one policy_evaluation (:300-336), for handles with a live-state list: under a FIXED
