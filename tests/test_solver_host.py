@@ -381,6 +381,70 @@ def test_sharded_solvers_keep_the_envs_order_unless_forced(monkeypatch):
     assert s._choose_memory_order() == (0, 2, 1, 3)
 
 
+def test_untuned_plugins_get_their_order_measured_and_tuned_classes_do_not(monkeypatch):
+    """Round 6: which solvers have their memory order MEASURED at construction (solver._tune_memory_order) — big
+    single-rank grids of a class without a MEMORY_ORDER of its own that runs the stock allocation; never a sharded solver, a
+    class with a tuple or "user", a small grid, or a subclass that replaces _allocate_tensors_and_compile."""
+    from dynamicprogramming_amd.solver import CudaPolicyIteration4D
+    calls = []
+
+    class Plugin(CudaPolicyIteration4D):                        # what a user of the reference writes
+        def _dynamics_cuda_src(self):
+            return ""
+
+        def _tune_memory_order(self):
+            calls.append(type(self).__name__)
+            return (0, 2, 1, 3)
+
+    class OwnAllocation(Plugin):
+        def _allocate_tensors_and_compile(self):
+            pass
+
+    class Tuned(Plugin):
+        MEMORY_ORDER = (1, 0, 2, 3)
+
+    class Measured(Plugin):
+        MEMORY_ORDER = "user"
+
+    def probe(cls, n_states, transport=None):
+        s = object.__new__(cls)
+        s.n_states, s._process_group, s._transport_arg = n_states, None, transport
+        return s._choose_memory_order()
+
+    class TwoRanks:
+        world, rank = 2, 0
+
+    assert probe(Plugin, 1 << 23) == (0, 2, 1, 3) and calls == ["Plugin"]
+    assert probe(Plugin, 1 << 20) is None                       # small grid: the env's order, nothing measured
+    assert probe(Plugin, 1 << 23, TwoRanks()) is None           # sharded: the env's order (halo rows stay contiguous)
+    assert probe(OwnAllocation, 1 << 23) is None                # builds its own device arrays: left alone
+    assert probe(Tuned, 1 << 23) == (1, 0, 2, 3) and probe(Measured, 1 << 23) is None
+    assert calls == ["Plugin"]
+    monkeypatch.setenv("PI_MI355_ORDER", "user")
+    assert probe(Plugin, 1 << 23) is None and calls == ["Plugin"]
+    monkeypatch.setenv("PI_MI355_ORDER", "auto")                # forces the measurement on any class and size
+    assert probe(Tuned, 1 << 10) == (0, 2, 1, 3) and calls == ["Plugin", "Tuned"]
+
+
+def test_candidate_orders_come_from_the_spread_of_a_waves_successors():
+    """The candidates `_tune_memory_order` times, from spreads as `_lane_spreads` measures them on the device (here: made
+    up after the double cartpole — x' = x + dt x_dot, so a wave along x_dot spreads over x, a wave along x does not
+    spread at all; angles and angular speeds spread over everything): the env's order first, the two tightest lane
+    dimensions each last, each with its partner second-fastest and every other dimension tried as the slowest."""
+    s = object.__new__(envs.ENVS["double_cartpole"])
+    big = {k: 2.0 for k in range(6)}
+    spread = {0: {k: 0.0 for k in range(6)}, 1: {0: 0.9, 1: 0.0, 2: 0.0, 3: 0.05, 4: 0.0, 5: 0.05},
+              2: dict(big), 3: dict(big), 4: dict(big), 5: dict(big)}
+    c = s._candidate_orders(spread)
+    assert c[0] == (0, 1, 2, 3, 4, 5) and len(c) == len(set(c)) == 11 and all(sorted(o) == list(range(6)) for o in c)
+    assert (1, 2, 3, 4, 5, 0) in c and (0, 2, 3, 4, 5, 1) in c                   # lanes along x, along x_dot, rest in order
+    for slow in (2, 3, 4, 5):                                                     # partner second-fastest, every other dim slowest
+        rest = [k for k in (2, 3, 4, 5) if k != slow]
+        assert tuple([slow] + rest + [0, 1]) in c and tuple([slow] + rest + [1, 0]) in c
+    two = object.__new__(envs.ENVS["pendulum"])
+    assert two._candidate_orders({0: {0: 0.0, 1: 3.0}, 1: {0: 0.5, 1: 0.0}}) == [(0, 1), (1, 0)]
+
+
 # ── property tests (hypothesis): the index algebra of the memory order and of the exchange planner ───────
 from hypothesis import given, settings, strategies as st  # noqa: E402
 
