@@ -429,10 +429,10 @@ def test_untuned_plugins_get_their_order_measured_and_tuned_classes_do_not(monke
 def test_candidate_orders_come_from_the_spread_of_a_waves_successors():
     """The candidates `_tune_memory_order` times, from spreads as `_lane_spreads` measures them on the device (here: made
     up after the double cartpole — x' = x + dt x_dot, so a wave along x_dot spreads over x, a wave along x does not
-    spread at all; angles and angular speeds spread over everything): the env's order first, the two tightest lane
+    spread at all; angles and angular speeds spread over each other): the env's order first, the two tightest lane
     dimensions each last, each with its partner second-fastest and every other dimension tried as the slowest."""
     s = object.__new__(envs.ENVS["double_cartpole"])
-    big = {k: 2.0 for k in range(6)}
+    big = {0: 0.0, 1: 0.3, 2: 2.0, 3: 2.0, 4: 2.0, 5: 2.0}     # the poles do not move the cart's position within one step
     spread = {0: {k: 0.0 for k in range(6)}, 1: {0: 0.9, 1: 0.0, 2: 0.0, 3: 0.05, 4: 0.0, 5: 0.05},
               2: dict(big), 3: dict(big), 4: dict(big), 5: dict(big)}
     c = s._candidate_orders(spread)
