@@ -407,7 +407,7 @@ class _CudaPolicyIterationBase(abc.ABC):
         D = self._D
         total = {d: sum(v for k, v in spread[d].items() if k != d) for d in range(D)}
         ranked = sorted(range(D), key=lambda d: (total[d], -d))
-        lanes = ranked[:2] if D >= 3 else ranked[:1]
+        lanes = ranked[:2]                                          # D = 2: both orders
         out = [tuple(range(D))]
         for lane in lanes:
             rest = [k for k in range(D) if k != lane]
