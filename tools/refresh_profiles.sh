@@ -7,7 +7,8 @@
 #   kernel_stats_bench_<cfg>.csv   rocprofv3 --kernel-trace --stats of the same command
 #   counters_real_c4.json          the same counters on a policy-iteration state of C4
 #   bench_<cfg>.json               the line `python bench.py [--env ... --bins ...]` prints
-#   kernel_stats_benchpy_c4.csv    rocprofv3 --kernel-trace --stats of the default bench command
+#   kernel_stats_benchpy_c4.csv    rocprofv3 --kernel-trace --stats of the bench command's timed region on the metric config alone
+#                                  (--no-extra-configs: the other configs run the same kernel names and would mix into the averages)
 # cfg = c2 (pendulum 200^2), c3 (cartpole swing-up 50^4), c4 (double pendulum 80^4: the metric config),
 #       c5 (double cartpole 25^6), c5_swingup (double cartpole swing-up 25^6).
 # Results land under gpurun_out/refresh/ (merged back by gpurun) AND are copied into profiles/rNN on the
@@ -37,7 +38,7 @@ rm -rf $O/*_p[0-9]/ $O/kstats_c*/
 fi
 if [ "$WHAT" != "counters" ]; then
 (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kstats_benchpy -- \
-    python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-converged-state --no-full-run > $R/$O/kstats_benchpy.log 2>&1)
+    python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-converged-state --no-full-run --no-extra-configs > $R/$O/kstats_benchpy.log 2>&1)
 cp $O/kstats_benchpy/*/*_kernel_stats.csv $O/kernel_stats_benchpy_c4.csv
 python3 bench.py > $O/bench_c4.json 2> $O/bench_c4.err
 python3 bench.py --env pendulum --bins 200 --steps 200 --warmup 20 > $O/bench_c2.json 2> $O/bench_c2.err
